@@ -1,0 +1,1182 @@
+/*
+ * mgoracle.c -- CPU restatement of the mgroms multigrid pressure solve.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.
+ *
+ * What it is: a plain-C (double precision, no FMA contraction, same loop and
+ * operation order) restatement of the reference's Fortran for the path
+ *   nhydro_init -> nhydro_matrices -> nhydro_solve -> nhydro_check_nondivergence
+ * Every routine cites the reference file:line it follows (paths relative to
+ * /root/reference/src).  MPI ranks are emulated inside one process: a "world"
+ * holds npx*npy rank states that advance in lock step, halo exchanges /
+ * all-gathers / all-reduces are memory copies between rank states.  This keeps
+ * the reference's decomposition-dependent behaviour (e.g. the order dependence
+ * of the red-black sweep at k=1) reproducible without MPI.
+ *
+ * Parity status: PINNED against outputs of the reference itself (flang -O2 +
+ * MPICH, run in the development container during the survey) recorded in
+ * BASELINE.md section 3 and committed as tests/golden/baseline_known_answers.json.
+ * The reference cannot be rebuilt under this round's rules (needs
+ * netcdf-fortran, which the image lacks, and a hand-written `mpi` module), so
+ * no oracle/_ref exists.
+ *
+ * Not restated (out of scope rows of SURVEY.md section 8): bmask=.true.
+ * (row f3), aggressive coarsening (unimplemented in the reference itself,
+ * mg_intergrids.f90:243), nz==1 levels (dead, mg_grids.f90:485), netcdf output.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MGO_GS 0
+#define MGO_RB 1
+#define MGO_FC 2
+
+typedef struct {
+  double solver_prec;  /* mg_namelist.f90:17 */
+  int solver_maxiter;  /* :18 */
+  int nsmall;          /* :11 */
+  int ns_coarsest;     /* :13 */
+  int ns_pre;          /* :14 */
+  int ns_post;         /* :15 */
+  int cmatrix_real;    /* :20  1='real' 0='simple' */
+  int relax_method;    /* :23  0=GS 1=RB 2=FC */
+  int interp_linear;   /* :27  1='linear' 0='nearest' */
+} mgo_params;
+
+/* one grid level of one rank: mg_grids.f90:24-65 */
+typedef struct {
+  int nx, ny, nz;
+  int npx, npy, incx, incy;
+  int gather, ngx, ngy, key, color;
+  int neighb[8]; /* S,E,N,W,SW,SE,NE,NW ; -1 = MPI_PROC_NULL */
+  double *cA;                 /* (8,nz,0:ny+1,0:nx+1) */
+  double *p, *b, *r;          /* (nz,0:ny+1,0:nx+1) */
+  double *dx, *dy, *zeta, *h; /* (0:ny+1,0:nx+1) */
+  double *zr;                 /* (nz,-1:ny+2,-1:nx+2) */
+  double *zw;                 /* (nz+1,-1:ny+2,-1:nx+2) */
+  double *cw;                 /* (nz+1,0:ny+1,0:nx+1) */
+  double *dzw, *zxdy, *zydx;  /* level 1 only */
+  double *dummy3;             /* (nz,0:nyc+1,0:nxc+1), gathered levels only */
+  double *tmp2[4];            /* pre-gather 2D scratch (dx,dy,zeta,h) */
+} olev;
+
+typedef struct {
+  int rank, pi, pj;
+  olev *lev;      /* [nlevs], index 0 = level 1 */
+  double *u, *v, *w; /* model arrays (i,j,k): u(1:nx+1,0:ny+1,1:nz) v(0:nx+1,1:ny+1,1:nz) w(0:nx+1,0:ny+1,0:nz) */
+  double *dum_nz, *dum_nzp; /* dummy3Dnz / dummy3Dnzp, level 1 */
+} orank;
+
+typedef struct {
+  mgo_params par;
+  int nlevs, npx, npy, nranks;
+  double hlim, theta_b, theta_s;
+  orank *rk;
+} oworld;
+
+/* ------------------------------------------------------------------ */
+/* index helpers (Fortran order, first index fastest)                   */
+#define I3(L, k, j, i) ((((size_t)(i)) * ((L)->ny + 2) + (j)) * (L)->nz + ((k)-1))
+#define I3P(L, k, j, i) ((((size_t)(i)) * ((L)->ny + 2) + (j)) * ((L)->nz + 1) + ((k)-1))
+#define ICA(L, s, k, j, i) (I3(L, k, j, i) * 8 + ((s)-1))
+#define I2(L, j, i) (((size_t)(i)) * ((L)->ny + 2) + (j))
+#define IZR(L, k, j, i) ((((size_t)((i) + 1)) * ((L)->ny + 4) + ((j) + 1)) * (L)->nz + ((k)-1))
+#define IZW(L, k, j, i) ((((size_t)((i) + 1)) * ((L)->ny + 4) + ((j) + 1)) * ((L)->nz + 1) + ((k)-1))
+
+static double *dalloc(size_t n) {
+  double *a = (double *)calloc(n ? n : 1, sizeof(double));
+  if (!a) { fprintf(stderr, "mgoracle: out of memory\n"); abort(); }
+  return a;
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_grids.f90:468-500 find_grid_levels                                */
+static int find_grid_levels(int npxg, int npyg, int nx, int ny, int nz) {
+  int nxg = npxg * nx, nyg = npyg * ny, nzg = nz;
+  int ncoarsest = 4, nzmin = 2;
+  int nhoriz = nxg < nyg ? nxg : nyg;
+  int nl1 = 1 + (int)floor(log(nhoriz * 1.0 / ncoarsest * 1.0) / log(2.0));
+  int nl2 = 1 + (int)floor(log(nzg * 1.0 / nzmin * 1.0) / log(2.0));
+  return nl1 < nl2 ? nl1 : nl2;
+}
+
+/* mg_grids.f90:503-577 define_grid_dims */
+static void define_grid_dims(oworld *W, orank *R, int nxl, int nyl, int nzl) {
+  int nx = nxl, ny = nyl, nz = nzl, npx = W->npx, npy = W->npy;
+  int incx = 1, incy = 1;
+  olev *L = &R->lev[0];
+  L->nx = nx; L->ny = ny; L->nz = nz; L->npx = npx; L->npy = npy;
+  L->incx = 1; L->incy = 1; L->gather = 0; L->ngx = 1; L->ngy = 1;
+  for (int lev = 2; lev <= W->nlevs; lev++) {
+    L = &R->lev[lev - 1];
+    if (nz == 1) { nx /= 2; ny /= 2; } else { nx /= 2; ny /= 2; nz /= 2; }
+    L->gather = 0; L->ngx = 1; L->ngy = 1;
+    if (((nx < ny ? nx : ny) < W->par.nsmall) && (npx * npy > 1)) {
+      L->gather = 1;
+      if (npx > 1) { npx /= 2; nx *= 2; L->ngx = 2; }
+      if (npy > 1) { npy /= 2; ny *= 2; L->ngy = 2; }
+      incx *= 2; incy *= 2;
+    }
+    L->nx = nx; L->ny = ny; L->nz = nz; L->npx = npx; L->npy = npy;
+    L->incx = incx; L->incy = incy;
+  }
+}
+
+/* mg_grids.f90:580-661 define_neighbours */
+static void define_neighbours(oworld *W, orank *R) {
+  int npx = W->npx, npy = W->npy, pi = R->pi, pj = R->pj;
+  for (int l = 0; l < W->nlevs; l++) {
+    olev *L = &R->lev[l];
+    int ix = L->incx, iy = L->incy;
+    L->neighb[0] = (pj >= iy) ? (pj - iy) * npx + pi : -1;
+    L->neighb[1] = (pi < npx - ix) ? pj * npx + pi + ix : -1;
+    L->neighb[2] = (pj < npy - iy) ? (pj + iy) * npx + pi : -1;
+    L->neighb[3] = (pi >= ix) ? pj * npx + pi - ix : -1;
+    L->neighb[4] = (pj >= iy && pi >= ix) ? (pj - iy) * npx + pi - ix : -1;
+    L->neighb[5] = (pj >= iy && pi < npx - ix) ? (pj - iy) * npx + pi + ix : -1;
+    L->neighb[6] = (pj < npy - iy && pi < npx - ix) ? (pj + iy) * npx + pi + ix : -1;
+    L->neighb[7] = (pj < npy - iy && pi >= ix) ? (pj + iy) * npx + pi - ix : -1;
+  }
+}
+
+/* mg_grids.f90:664-738 define_gather_informations (colour/key arithmetic) */
+static void define_gather_informations(oworld *W, orank *R) {
+  int npx = W->npx, pi = R->pi, pj = R->pj;
+  for (int l = 1; l < W->nlevs; l++) {
+    olev *L = &R->lev[l];
+    if (!L->gather) continue;
+    int incx = L->incx / 2, incy = L->incy / 2;
+    int family = (pi / incx) * incx * incy + npx * incy * (pj / incy);
+    int nextfamily = (pi / (2 * incx)) * incx * incy * 4 + npx * 2 * incy * (pj / (incy * 2));
+    L->color = nextfamily + (pi % incx) + (pj % incy) * incx;
+    int N = incx * npx;
+    L->key = ((family % N) / (incx * incy)) % 2 + 2 * ((family / N) % 2);
+    int nxc = L->nx / L->ngx, nyc = L->ny / L->ngy;
+    L->dummy3 = dalloc((size_t)L->nz * (nyc + 2) * (nxc + 2));
+    for (int q = 0; q < 4; q++) L->tmp2[q] = dalloc((size_t)(nyc + 2) * (nxc + 2));
+  }
+}
+
+/* members of rank r's gather group at level index l, ordered by (key, rank):
+ * emulates MPI_COMM_SPLIT(color,key) + MPI_ALLGATHER ordering, mg_grids.f90:717 */
+static int gather_group(oworld *W, int r, int l, int *members) {
+  int n = 0, col = W->rk[r].lev[l].color;
+  for (int q = 0; q < W->nranks; q++)
+    if (W->rk[q].lev[l].color == col) members[n++] = q;
+  for (int a = 1; a < n; a++) { /* insertion sort by key (ranks already ascending) */
+    int m = members[a], b = a - 1;
+    while (b >= 0 && W->rk[members[b]].lev[l].key > W->rk[m].lev[l].key) { members[b + 1] = members[b]; b--; }
+    members[b + 1] = m;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* generic halo fill on an array a(nzz, 1-nh:ny+nh, 1-nh:nx+nh)          */
+/* mg_mpi_exchange.f90:23-352 (2D), :396-745 (3D relax), :750-1242 (3D)  */
+typedef double *(*field_fn)(olev *);
+typedef struct { int nzz, nh; char lbc; int which; } halo_desc;
+
+static inline size_t IH(const olev *L, const halo_desc *d, int k, int j, int i) {
+  return (((size_t)(i + d->nh - 1)) * (L->ny + 2 * d->nh) + (j + d->nh - 1)) * d->nzz + (k - 1);
+}
+
+/* phase 1: physical-boundary fills done before the sends are packed */
+static void halo_phase1(olev *L, double *a, const halo_desc *d) {
+  int nx = L->nx, ny = L->ny, nh = d->nh, nzz = d->nzz;
+  int S = L->neighb[0], E = L->neighb[1], N = L->neighb[2], Wn = L->neighb[3];
+  int SW = L->neighb[4], SE = L->neighb[5], NE = L->neighb[6], NW = L->neighb[7];
+  char c = d->lbc;
+#define A(k, j, i) a[IH(L, d, k, j, i)]
+  if (S < 0) {
+    if (c == 'v') { for (int i = 1 - nh; i <= nx + nh; i++) for (int k = 1; k <= nzz; k++) A(k, 1, i) = 0.0; }
+    else for (int i = 1; i <= nx; i++) for (int k = 1; k <= nzz; k++) {
+      A(k, 0, i) = A(k, 1, i);
+      if (nh == 2) A(k, -1, i) = 2.0 * A(k, 1, i) - A(k, 2, i);
+    }
+  }
+  if (E < 0) {
+    if (c == 'u') { for (int j = 1 - nh; j <= ny + nh; j++) for (int k = 1; k <= nzz; k++) A(k, j, nx + 1) = 0.0; }
+    else for (int j = 1; j <= ny; j++) for (int k = 1; k <= nzz; k++) {
+      A(k, j, nx + 1) = A(k, j, nx);
+      if (nh == 2) A(k, j, nx + 2) = 2.0 * A(k, j, nx) - A(k, j, nx - 1);
+    }
+  }
+  if (N < 0) {
+    if (c == 'v') { for (int i = 1 - nh; i <= nx + nh; i++) for (int k = 1; k <= nzz; k++) A(k, ny + 1, i) = 0.0; }
+    else for (int i = 1; i <= nx; i++) for (int k = 1; k <= nzz; k++) {
+      A(k, ny + 1, i) = A(k, ny, i);
+      if (nh == 2) A(k, ny + 2, i) = 2.0 * A(k, ny, i) - A(k, ny - 1, i);
+    }
+  }
+  if (Wn < 0) {
+    if (c == 'u') { for (int j = 1 - nh; j <= ny + nh; j++) for (int k = 1; k <= nzz; k++) A(k, j, 1) = 0.0; }
+    else for (int j = 1; j <= ny; j++) for (int k = 1; k <= nzz; k++) {
+      A(k, j, 0) = A(k, j, 1);
+      if (nh == 2) A(k, j, -1) = 2.0 * A(k, j, 1) - A(k, j, 2);
+    }
+  }
+  /* corners: zero (lbc), deferred flag, or diagonal mirror p(:,1-nh:0,1-nh:0)=p(:,nh:1:-1,nh:1:-1) */
+  if (SW < 0) {
+    if (c == 'u' && Wn < 0) { for (int ii = 1 - nh; ii <= 0; ii++) for (int jj = 1 - nh; jj <= 0; jj++) for (int k = 1; k <= nzz; k++) A(k, jj, ii) = 0.0; }
+    else if (S < 0 && Wn < 0) for (int ii = 0; ii < nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, -jj, -ii) = A(k, 1 + jj, 1 + ii);
+  }
+  if (SE < 0) {
+    if (c == 'u' && E < 0) { for (int ii = 1; ii <= nh; ii++) for (int jj = 1 - nh; jj <= 0; jj++) for (int k = 1; k <= nzz; k++) A(k, jj, nx + ii) = 0.0; }
+    else if (S < 0 && E < 0) for (int ii = 0; ii < nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, -jj, nx + 1 + ii) = A(k, 1 + jj, nx - ii);
+  }
+  if (NE < 0) {
+    if ((c == 'u' && E < 0) || c == 'v') { for (int ii = 1; ii <= nh; ii++) for (int jj = 1; jj <= nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + jj, nx + ii) = 0.0; }
+    else if (N < 0 && E < 0) for (int ii = 0; ii < nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + 1 + jj, nx + 1 + ii) = A(k, ny - jj, nx - ii);
+  }
+  if (NW < 0) {
+    if ((c == 'u' && Wn < 0) || c == 'v') { for (int ii = 1 - nh; ii <= 0; ii++) for (int jj = 1; jj <= nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + jj, ii) = 0.0; }
+    else if (N < 0 && Wn < 0) for (int ii = 0; ii < nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + 1 + jj, -ii) = A(k, ny - jj, 1 + ii);
+  }
+#undef A
+}
+
+/* phase 2: receive = copy the neighbour's interior edge (its packed send buffer) */
+static void halo_phase2(oworld *W, int r, int l, field_fn f, const halo_desc *d) {
+  olev *L = &W->rk[r].lev[l];
+  double *a = f(L);
+  int nx = L->nx, ny = L->ny, nh = d->nh, nzz = d->nzz;
+#define A(k, j, i) a[IH(L, d, k, j, i)]
+#define B(k, j, i) bsrc[IH(Ln, d, k, j, i)]
+  for (int dir = 0; dir < 8; dir++) {
+    int q = L->neighb[dir];
+    if (q < 0) continue;
+    olev *Ln = &W->rk[q].lev[l];
+    const double *bsrc = f(Ln);
+    int j0, j1, i0, i1, sj, si; /* my halo range and shift into neighbour's index space */
+    switch (dir) {
+      case 0: j0 = 1 - nh; j1 = 0; i0 = 1; i1 = nx; sj = ny; si = 0; break;           /* south: his rows ny-nh+1:ny */
+      case 1: j0 = 1; j1 = ny; i0 = nx + 1; i1 = nx + nh; sj = 0; si = -nx; break;     /* east: his cols 1:nh */
+      case 2: j0 = ny + 1; j1 = ny + nh; i0 = 1; i1 = nx; sj = -ny; si = 0; break;     /* north */
+      case 3: j0 = 1; j1 = ny; i0 = 1 - nh; i1 = 0; sj = 0; si = nx; break;            /* west */
+      case 4: j0 = 1 - nh; j1 = 0; i0 = 1 - nh; i1 = 0; sj = ny; si = nx; break;       /* SW */
+      case 5: j0 = 1 - nh; j1 = 0; i0 = nx + 1; i1 = nx + nh; sj = ny; si = -nx; break;/* SE */
+      case 6: j0 = ny + 1; j1 = ny + nh; i0 = nx + 1; i1 = nx + nh; sj = -ny; si = -nx; break; /* NE */
+      default: j0 = ny + 1; j1 = ny + nh; i0 = 1 - nh; i1 = 0; sj = -ny; si = nx; break;       /* NW */
+    }
+    for (int i = i0; i <= i1; i++) for (int j = j0; j <= j1; j++) for (int k = 1; k <= nzz; k++)
+      A(k, j, i) = B(k, j + sj, i + si);
+  }
+#undef B
+  /* phase 3: mixed corners copied from the already filled edge halo, mg_mpi_exchange.f90:720-743 */
+  int S = L->neighb[0], E = L->neighb[1], N = L->neighb[2], Wn = L->neighb[3];
+  int SW = L->neighb[4], SE = L->neighb[5], NE = L->neighb[6], NW = L->neighb[7];
+  char c = d->lbc;
+  if (SW < 0 && !(c == 'u' && Wn < 0)) {
+    if (S >= 0) { for (int ii = 0; ii < nh; ii++) for (int jj = 1 - nh; jj <= 0; jj++) for (int k = 1; k <= nzz; k++) A(k, jj, -ii) = A(k, jj, 1 + ii); }
+    else if (Wn >= 0) { for (int ii = 1 - nh; ii <= 0; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, -jj, ii) = A(k, 1 + jj, ii); }
+  }
+  if (SE < 0 && !(c == 'u' && E < 0)) {
+    if (S >= 0) { for (int ii = 0; ii < nh; ii++) for (int jj = 1 - nh; jj <= 0; jj++) for (int k = 1; k <= nzz; k++) A(k, jj, nx + 1 + ii) = A(k, jj, nx - ii); }
+    else if (E >= 0) { for (int ii = 1; ii <= nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, -jj, nx + ii) = A(k, 1 + jj, nx + ii); }
+  }
+  if (NE < 0 && !((c == 'u' && E < 0) || c == 'v')) {
+    if (N >= 0) { for (int ii = 0; ii < nh; ii++) for (int jj = 1; jj <= nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + jj, nx + 1 + ii) = A(k, ny + jj, nx - ii); }
+    else if (E >= 0) { for (int ii = 1; ii <= nh; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + 1 + jj, nx + ii) = A(k, ny - jj, nx + ii); }
+  }
+  if (NW < 0 && !((c == 'u' && Wn < 0) || c == 'v')) {
+    if (N >= 0) { for (int ii = 0; ii < nh; ii++) for (int jj = 1; jj <= nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + jj, -ii) = A(k, ny + jj, 1 + ii); }
+    else if (Wn >= 0) { for (int ii = 1 - nh; ii <= 0; ii++) for (int jj = 0; jj < nh; jj++) for (int k = 1; k <= nzz; k++) A(k, ny + 1 + jj, ii) = A(k, ny - jj, ii); }
+  }
+#undef A
+}
+
+static void fill_halo_all(oworld *W, int l, field_fn f, halo_desc d) {
+  for (int r = 0; r < W->nranks; r++) halo_phase1(&W->rk[r].lev[l], f(&W->rk[r].lev[l]), &d);
+  for (int r = 0; r < W->nranks; r++) halo_phase2(W, r, l, f, &d);
+}
+
+static double *f_p(olev *L) { return L->p; }
+static double *f_b(olev *L) { return L->b; }
+static double *f_r(olev *L) { return L->r; }
+static double *f_dx(olev *L) { return L->dx; }
+static double *f_dy(olev *L) { return L->dy; }
+static double *f_zeta(olev *L) { return L->zeta; }
+static double *f_h(olev *L) { return L->h; }
+static double *f_zr(olev *L) { return L->zr; }
+static double *f_zw(olev *L) { return L->zw; }
+static double *f_dummy3(olev *L) { return L->dummy3; }
+
+static halo_desc HD(int nzz, int nh, char c) { halo_desc d; d.nzz = nzz; d.nh = nh; d.lbc = c; d.which = 0; return d; }
+
+/* ------------------------------------------------------------------ */
+/* mg_zr_zw.f90:98-170 setup_zr_zw_croco, branch 'new_s_coord' (computed on 0:n+1 only, :91) */
+static void setup_zr_zw(oworld *W, olev *L) {
+  int nx = L->nx, ny = L->ny, nz = L->nz;
+  double hlim = W->hlim, theta_b = W->theta_b, theta_s = W->theta_s;
+  const double one = 1.0, hlf = 0.5, nul = 0.0;
+  for (int i = 0; i <= nx + 1; i++)
+    for (int j = 0; j <= ny + 1; j++) {
+      double cff = one / (double)nz;
+      double h = L->h[I2(L, j, i)], zeta = L->zeta[I2(L, j, i)];
+      double hinv = one / (h + hlim);
+      double sc_w, sc_r, csrf, cswf, cs_r, cs_w, cff_w, cff_r, z_w0, z_r0;
+      for (int k = 1; k <= nz; k++) {
+        sc_r = cff * ((double)(k - nz) - hlf);
+        if (theta_s > nul) csrf = (one - cosh(theta_s * sc_r)) / (cosh(theta_s) - one);
+        else csrf = -(sc_r * sc_r);
+        if (theta_b > nul) cs_r = (exp(theta_b * csrf) - one) / (one - exp(-theta_b));
+        else cs_r = csrf;
+        sc_w = cff * (double)(k - 1 - nz);
+        if (theta_s > nul) cswf = (one - cosh(theta_s * sc_w)) / (cosh(theta_s) - one);
+        else cswf = -(sc_w * sc_w);
+        if (theta_b > nul) cs_w = (exp(theta_b * cswf) - one) / (one - exp(-theta_b));
+        else cs_w = cswf;
+        cff_w = hlim * sc_w;
+        cff_r = hlim * sc_r;
+        z_w0 = cff_w + cs_w * h;
+        z_r0 = cff_r + cs_r * h;
+        L->zw[IZW(L, k, j, i)] = z_w0 * h * hinv + zeta * (1. + z_w0 * hinv);
+        L->zr[IZR(L, k, j, i)] = z_r0 * h * hinv + zeta * (1. + z_r0 * hinv);
+      }
+      int k = nz + 1;
+      sc_w = cff * (double)(k - 1 - nz);
+      if (theta_s > nul) cswf = (one - cosh(theta_s * sc_w)) / (cosh(theta_s) - one);
+      else cswf = -(sc_w * sc_w);
+      if (theta_b > nul) cs_w = (exp(theta_b * cswf) - one) / (one - exp(-theta_b));
+      else cs_w = cswf;
+      cff_w = hlim * sc_w;
+      z_w0 = cff_w + cs_w * h;
+      L->zw[IZW(L, k, j, i)] = z_w0 * h * hinv + zeta * (1. + z_w0 * hinv);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_define_matrix.f90:211-680 define_matrix (bmask=.false.: umask=vmask=1) */
+static void define_matrix(olev *L, int lev) {
+  int nx = L->nx, ny = L->ny, nz = L->nz;
+  const double one = 1.0, qrt = 0.25, hlf = 0.5;
+  double *cA = L->cA, *cw = L->cw;
+#define ZR(k, j, i) L->zr[IZR(L, k, j, i)]
+#define ZW(k, j, i) L->zw[IZW(L, k, j, i)]
+#define DX(j, i) L->dx[I2(L, j, i)]
+#define DY(j, i) L->dy[I2(L, j, i)]
+#define CW(k, j, i) cw[I3P(L, k, j, i)]
+#define CA(s, k, j, i) cA[ICA(L, s, k, j, i)]
+  if (lev == 1) { /* :283-306 */
+    for (int i = 0; i <= nx + 1; i++)
+      for (int j = 0; j <= ny + 1; j++) {
+        L->dzw[I3P(L, 1, j, i)] = ZR(1, j, i) - ZW(1, j, i);
+        for (int k = 2; k <= nz; k++) L->dzw[I3P(L, k, j, i)] = ZR(k, j, i) - ZR(k - 1, j, i);
+        L->dzw[I3P(L, nz + 1, j, i)] = ZW(nz + 1, j, i) - ZR(nz, j, i);
+      }
+    for (int i = 0; i <= nx + 1; i++)
+      for (int j = 0; j <= ny + 1; j++)
+        for (int k = 1; k <= nz; k++) {
+          L->zydx[I3(L, k, j, i)] = hlf * ((ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
+          L->zxdy[I3(L, k, j, i)] = hlf * ((ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
+        }
+  }
+  /* cw :309-336 */
+  for (int i = 0; i <= nx + 1; i++)
+    for (int j = 0; j <= ny + 1; j++) {
+      double Arz = DX(j, i) * DY(j, i);
+      int k = 1;
+      double sx, sy;
+      sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
+      sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
+      CW(k, j, i) = (Arz / (ZR(k, j, i) - ZW(k, j, i))) * (one + sx * sx + sy * sy);
+      for (k = 2; k <= nz; k++) {
+        sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
+        sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
+        CW(k, j, i) = (Arz / (ZR(k, j, i) - ZR(k - 1, j, i))) * (one + sx * sx + sy * sy);
+      }
+      k = nz + 1;
+      sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
+      sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
+      CW(k, j, i) = (Arz / (ZW(k, j, i) - ZR(k - 1, j, i))) * (one + sx * sx + sy * sy);
+    }
+  /* k = 1 :352-485 */
+  int k = 1;
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny + 1; j++) {
+      CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
+                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+      double t1 = ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+      double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i));
+      CA(4, k, j, i) =
+          (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i))) /
+              (hlf * (DY(j, i) + DY(j - 1, i)))
+          - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)))
+          - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i) -
+                   (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+    }
+  for (int i = 1; i <= nx + 1; i++)
+    for (int j = 1; j <= ny; j++) {
+      CA(6, k, j, i) = qrt * ((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i) +
+                              (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * one;
+      double t1 = ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+      double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1));
+      CA(7, k, j, i) =
+          (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1))) /
+              (hlf * (DX(j, i) + DX(j, i - 1)))
+          - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)))
+          - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1) -
+                   (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+    }
+  for (int i = 1; i <= nx + 1; i++)
+    for (int j = 0; j <= ny; j++) {
+      CA(5, k, j, i) =
+          +hlf * ((hlf * (ZR(k, j + 1, i + 1) - ZR(k, j + 1, i - 1)) / DX(j + 1, i)) * DY(j + 1, i)) *
+                  ((hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)) /
+                  (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * one * one
+          + hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                  ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+    }
+  for (int i = 1; i <= nx + 1; i++)
+    for (int j = 1; j <= ny + 1; j++) {
+      CA(8, k, j, i) =
+          -hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
+                  ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
+                  (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * one * one
+          - hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                  ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+    }
+  /* k = 2..nz-1 :492-559 */
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny; j++)
+      for (k = 2; k <= nz - 1; k++) CA(2, k, j, i) = CW(k, j, i);
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny + 1; j++)
+      for (k = 2; k <= nz - 1; k++) {
+        CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
+                                (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+        CA(4, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) *
+                          (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * one;
+        CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
+                                 ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+      }
+  for (int i = 1; i <= nx + 1; i++)
+    for (int j = 1; j <= ny; j++)
+      for (k = 2; k <= nz - 1; k++) {
+        CA(6, k, j, i) = qrt * (((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                                ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+        CA(7, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) *
+                          (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * one;
+        CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                                 ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+      }
+  /* k = nz :565-609 */
+  k = nz;
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny; j++) CA(2, k, j, i) = CW(k, j, i);
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny + 1; j++) {
+      CA(4, k, j, i) =
+          (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) /
+               (hlf * (DY(j, i) + DY(j - 1, i)))
+           + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))
+                    + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * one;
+      CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
+                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+    }
+  for (int i = 1; i <= nx + 1; i++)
+    for (int j = 1; j <= ny; j++) {
+      CA(7, k, j, i) =
+          (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) /
+               (hlf * (DX(j, i) + DX(j, i - 1)))
+           + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))
+                    + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * one;
+      CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+    }
+  /* diagonal :616-657 */
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny; j++) {
+      k = 1;
+      CA(1, k, j, i) = -CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
+                       - CA(6, k, j, i) - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(5, k + 1, j + 1, i)
+                       - CA(5, k, j, i) - CA(5, k, j - 1, i + 1) - CA(8, k, j, i) - CA(8, k, j + 1, i + 1);
+      for (k = 2; k <= nz - 1; k++)
+        CA(1, k, j, i) = -CA(2, k, j, i) - CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i)
+                         - CA(7, k, j, i + 1) - CA(6, k, j, i) - CA(6, k - 1, j, i + 1) - CA(8, k, j, i)
+                         - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i)
+                         - CA(5, k + 1, j + 1, i);
+      k = nz;
+      CA(1, k, j, i) = -CA(2, k, j, i) - CW(k + 1, j, i)
+                       + hlf * (hlf * (ZR(k, j, i + 2) - ZR(k, j, i)) / DX(j, i + 1)) * DY(j, i + 1)
+                       - hlf * (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)
+                       + hlf * (hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)
+                       - hlf * (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)
+                       - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
+                       - CA(6, k - 1, j, i + 1) - CA(8, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i);
+    }
+#undef ZR
+#undef ZW
+#undef DX
+#undef DY
+#undef CW
+#undef CA
+}
+
+/* mg_gather.f90:18-92 gather_2D / :95-174 gather_3D: interior-only copy of the members' blocks */
+static void gather_into(oworld *W, int r, int l, int nzz, int which2d, double *dst) {
+  olev *L = &W->rk[r].lev[l];
+  int members[4];
+  int n = gather_group(W, r, l, members);
+  int nxc = L->nx / L->ngx, nyc = L->ny / L->ngy;
+  for (int q = 0; q < n; q++) {
+    int lq = q % L->ngx, mq = q / L->ngx;
+    olev *Lq = &W->rk[members[q]].lev[l];
+    const double *src = (which2d >= 0) ? Lq->tmp2[which2d] : Lq->dummy3;
+    for (int i = 1; i <= nxc; i++)
+      for (int j = 1; j <= nyc; j++)
+        for (int k = 1; k <= nzz; k++)
+          dst[(((size_t)(i + lq * nxc)) * (L->ny + 2) + (j + mq * nyc)) * nzz + (k - 1)] =
+              src[(((size_t)i) * (nyc + 2) + j) * nzz + (k - 1)];
+  }
+}
+
+/* mg_define_matrix.f90:28-208 define_matrices_topo */
+static void define_matrices(oworld *W) {
+  for (int l = 0; l < W->nlevs; l++) {
+    if (l > 0) {
+      for (int r = 0; r < W->nranks; r++) { /* coarsen dx,dy,zeta,h :116-138 */
+        olev *L = &W->rk[r].lev[l], *F = &W->rk[r].lev[l - 1];
+        int nxc = L->gather ? L->nx / L->ngx : L->nx;
+        int nyc = L->gather ? L->ny / L->ngy : L->ny;
+        double *dst[4] = {L->gather ? L->tmp2[0] : L->dx, L->gather ? L->tmp2[1] : L->dy,
+                          L->gather ? L->tmp2[2] : L->zeta, L->gather ? L->tmp2[3] : L->h};
+        const double *src[4] = {F->dx, F->dy, F->zeta, F->h};
+        const double fac[4] = {0.5, 0.5, 0.25, 0.25};
+        for (int q = 0; q < 4; q++)
+          for (int i = 1; i <= nxc; i++)
+            for (int j = 1; j <= nyc; j++) {
+              int fi = 2 * i - 1, fj = 2 * j - 1;
+              dst[q][((size_t)i) * (nyc + 2) + j] =
+                  fac[q] * (src[q][I2(F, fj, fi)] + src[q][I2(F, fj + 1, fi)] + src[q][I2(F, fj, fi + 1)] +
+                            src[q][I2(F, fj + 1, fi + 1)]);
+            }
+      }
+      for (int r = 0; r < W->nranks; r++) { /* gather :142-153 */
+        olev *L = &W->rk[r].lev[l];
+        if (!L->gather) continue;
+        gather_into(W, r, l, 1, 0, L->dx);
+        gather_into(W, r, l, 1, 1, L->dy);
+        gather_into(W, r, l, 1, 2, L->zeta);
+        gather_into(W, r, l, 1, 3, L->h);
+      }
+    }
+    fill_halo_all(W, l, f_dx, HD(1, 1, 0)); /* :165-168 */
+    fill_halo_all(W, l, f_dy, HD(1, 1, 0));
+    fill_halo_all(W, l, f_zeta, HD(1, 1, 0));
+    fill_halo_all(W, l, f_h, HD(1, 1, 0));
+    for (int r = 0; r < W->nranks; r++) setup_zr_zw(W, &W->rk[r].lev[l]); /* :174-178 */
+    fill_halo_all(W, l, f_zr, HD(W->rk[0].lev[l].nz, 2, 0));              /* :184 */
+    fill_halo_all(W, l, f_zw, HD(W->rk[0].lev[l].nz + 1, 2, 0));          /* :185 */
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < W->nranks; r++) define_matrix(&W->rk[r].lev[l], l + 1); /* :202 */
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_relax.f90:237-305 relax_3D_8_heart + :308-334 tridiag             */
+static void relax_heart(const olev *L, int i, int j, int real, double *rhs, double *d, double *ud, double *gam) {
+  int nz = L->nz;
+  double *p = L->p;
+  const double *b = L->b, *cA = L->cA;
+#define P(k, j, i) p[I3(L, k, j, i)]
+#define B(k, j, i) b[I3(L, k, j, i)]
+#define CA(s, k, j, i) cA[ICA(L, s, k, j, i)]
+  int k = 1;
+  rhs[k] = B(k, j, i) - CA(3, k, j, i) * P(k + 1, j - 1, i) - CA(4, k, j, i) * P(k, j - 1, i) -
+           CA(4, k, j + 1, i) * P(k, j + 1, i) - CA(5, k + 1, j + 1, i) * P(k + 1, j + 1, i) -
+           CA(6, k, j, i) * P(k + 1, j, i - 1) - CA(7, k, j, i) * P(k, j, i - 1) - CA(7, k, j, i + 1) * P(k, j, i + 1) -
+           CA(8, k + 1, j, i + 1) * P(k + 1, j, i + 1);
+  if (real)
+    rhs[k] = rhs[k] - CA(5, k, j, i) * P(k, j + 1, i - 1) - CA(5, k, j - 1, i + 1) * P(k, j - 1, i + 1) -
+             CA(8, k, j, i) * P(k, j - 1, i - 1) - CA(8, k, j + 1, i + 1) * P(k, j + 1, i + 1);
+  d[k] = CA(1, k, j, i);
+  ud[k] = CA(2, k + 1, j, i);
+  for (k = 2; k <= nz - 1; k++) {
+    rhs[k] = B(k, j, i) - CA(3, k, j, i) * P(k + 1, j - 1, i) - CA(3, k - 1, j + 1, i) * P(k - 1, j + 1, i) -
+             CA(4, k, j, i) * P(k, j - 1, i) - CA(4, k, j + 1, i) * P(k, j + 1, i) -
+             CA(5, k, j, i) * P(k - 1, j - 1, i) - CA(5, k + 1, j + 1, i) * P(k + 1, j + 1, i) -
+             CA(6, k, j, i) * P(k + 1, j, i - 1) - CA(6, k - 1, j, i + 1) * P(k - 1, j, i + 1) -
+             CA(7, k, j, i) * P(k, j, i - 1) - CA(7, k, j, i + 1) * P(k, j, i + 1) -
+             CA(8, k, j, i) * P(k - 1, j, i - 1) - CA(8, k + 1, j, i + 1) * P(k + 1, j, i + 1);
+    d[k] = CA(1, k, j, i);
+    ud[k] = CA(2, k + 1, j, i);
+  }
+  k = nz;
+  rhs[k] = B(k, j, i) - CA(3, k - 1, j + 1, i) * P(k - 1, j + 1, i) - CA(4, k, j, i) * P(k, j - 1, i) -
+           CA(4, k, j + 1, i) * P(k, j + 1, i) - CA(5, k, j, i) * P(k - 1, j - 1, i) -
+           CA(6, k - 1, j, i + 1) * P(k - 1, j, i + 1) - CA(7, k, j, i) * P(k, j, i - 1) -
+           CA(7, k, j, i + 1) * P(k, j, i + 1) - CA(8, k, j, i) * P(k - 1, j, i - 1);
+  d[k] = CA(1, k, j, i);
+  /* tridiag(nz,d,ud,rhs,p(:,j,i)) */
+  double bet = 1.0 / d[1];
+  P(1, j, i) = rhs[1] * bet;
+  for (k = 2; k <= nz; k++) {
+    gam[k] = ud[k - 1] * bet;
+    bet = 1.0 / (d[k] - ud[k - 1] * gam[k]);
+    P(k, j, i) = (rhs[k] - ud[k - 1] * P(k - 1, j, i)) * bet;
+  }
+  for (k = nz - 1; k >= 1; k--) P(k, j, i) = P(k, j, i) - gam[k + 1] * P(k + 1, j, i);
+#undef P
+#undef B
+#undef CA
+}
+
+/* mg_relax.f90:16-47 relax, :116-148 GS, :151-190 RB, :193-234 FC */
+static void relax_level(oworld *W, int lev, int nsweeps) {
+  int l = lev - 1, method = W->par.relax_method, real = W->par.cmatrix_real;
+  int nz = W->rk[0].lev[l].nz;
+  for (int it = 1; it <= nsweeps; it++) {
+    int ncol = method == MGO_GS ? 1 : (method == MGO_RB ? 2 : 4);
+    for (int c = 0; c < ncol; c++) {
+#pragma omp parallel for schedule(static)
+      for (int r = 0; r < W->nranks; r++) {
+        olev *L = &W->rk[r].lev[l];
+        int nx = L->nx, ny = L->ny;
+        double *wk = (double *)malloc(sizeof(double) * 4 * (nz + 2));
+        double *rhs = wk, *d = wk + (nz + 2), *ud = wk + 2 * (nz + 2), *gam = wk + 3 * (nz + 2);
+        if (method == MGO_GS) {
+          for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) relax_heart(L, i, j, real, rhs, d, ud, gam);
+        } else if (method == MGO_RB) {
+          int rb = c + 1;
+          for (int i = 1; i <= nx; i++) for (int j = 1 + (i + rb) % 2; j <= ny; j += 2) relax_heart(L, i, j, real, rhs, d, ud, gam);
+        } else {
+          int fc1 = c / 2 + 1, fc2 = c % 2 + 1;
+          for (int i = 1 + (fc1 - 1) % 2; i <= nx; i += 2)
+            for (int j = 1 + (fc2 - 1) % 2; j <= ny; j += 2) relax_heart(L, i, j, real, rhs, d, ud, gam);
+        }
+        free(wk);
+      }
+      fill_halo_all(W, l, f_p, HD(nz, 1, 0)); /* fill_halo_3D_relax after each colour */
+    }
+  }
+}
+
+/* mg_relax.f90:421-515 compute_residual_3D_8 ; :337-383 compute_residual */
+static double residual_local(const olev *L, int real) {
+  int nx = L->nx, ny = L->ny, nz = L->nz;
+  const double *p = L->p, *b = L->b, *cA = L->cA;
+  double *r = L->r, res = 0.0;
+#define P(k, j, i) p[I3(L, k, j, i)]
+#define B(k, j, i) b[I3(L, k, j, i)]
+#define R(k, j, i) r[I3(L, k, j, i)]
+#define CA(s, k, j, i) cA[ICA(L, s, k, j, i)]
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny; j++) {
+      int k = 1;
+      R(k, j, i) = B(k, j, i) - CA(1, k, j, i) * P(k, j, i) - CA(2, k + 1, j, i) * P(k + 1, j, i) -
+                   CA(3, k, j, i) * P(k + 1, j - 1, i) - CA(4, k, j, i) * P(k, j - 1, i) -
+                   CA(4, k, j + 1, i) * P(k, j + 1, i) - CA(5, k + 1, j + 1, i) * P(k + 1, j + 1, i) -
+                   CA(6, k, j, i) * P(k + 1, j, i - 1) - CA(7, k, j, i) * P(k, j, i - 1) -
+                   CA(7, k, j, i + 1) * P(k, j, i + 1) - CA(8, k + 1, j, i + 1) * P(k + 1, j, i + 1);
+      if (real)
+        R(k, j, i) = R(k, j, i) - CA(5, k, j, i) * P(k, j + 1, i - 1) - CA(5, k, j - 1, i + 1) * P(k, j - 1, i + 1) -
+                     CA(8, k, j, i) * P(k, j - 1, i - 1) - CA(8, k, j + 1, i + 1) * P(k, j + 1, i + 1);
+      res = res + R(k, j, i) * R(k, j, i);
+      for (k = 2; k <= nz - 1; k++) {
+        R(k, j, i) = B(k, j, i) - CA(1, k, j, i) * P(k, j, i) - CA(2, k, j, i) * P(k - 1, j, i) -
+                     CA(2, k + 1, j, i) * P(k + 1, j, i) - CA(3, k, j, i) * P(k + 1, j - 1, i) -
+                     CA(3, k - 1, j + 1, i) * P(k - 1, j + 1, i) - CA(4, k, j, i) * P(k, j - 1, i) -
+                     CA(4, k, j + 1, i) * P(k, j + 1, i) - CA(5, k, j, i) * P(k - 1, j - 1, i) -
+                     CA(5, k + 1, j + 1, i) * P(k + 1, j + 1, i) - CA(6, k, j, i) * P(k + 1, j, i - 1) -
+                     CA(6, k - 1, j, i + 1) * P(k - 1, j, i + 1) - CA(7, k, j, i) * P(k, j, i - 1) -
+                     CA(7, k, j, i + 1) * P(k, j, i + 1) - CA(8, k, j, i) * P(k - 1, j, i - 1) -
+                     CA(8, k + 1, j, i + 1) * P(k + 1, j, i + 1);
+        res = res + R(k, j, i) * R(k, j, i);
+      }
+      k = nz;
+      R(k, j, i) = B(k, j, i) - CA(1, k, j, i) * P(k, j, i) - CA(2, k, j, i) * P(k - 1, j, i) -
+                   CA(3, k - 1, j + 1, i) * P(k - 1, j + 1, i) - CA(4, k, j, i) * P(k, j - 1, i) -
+                   CA(4, k, j + 1, i) * P(k, j + 1, i) - CA(5, k, j, i) * P(k - 1, j - 1, i) -
+                   CA(6, k - 1, j, i + 1) * P(k - 1, j, i + 1) - CA(7, k, j, i) * P(k, j, i - 1) -
+                   CA(7, k, j, i + 1) * P(k, j, i + 1) - CA(8, k, j, i) * P(k - 1, j, i - 1);
+      res = res + R(k, j, i) * R(k, j, i);
+    }
+#undef P
+#undef B
+#undef R
+#undef CA
+  return res;
+}
+
+/* mg_mpi_exchange.f90:1555-1571 global_sum (rank-order sum, then the gathered-level rescale) */
+static double global_sum(oworld *W, int l, const double *loc) {
+  double s = 0.0;
+  for (int r = 0; r < W->nranks; r++) s += loc[r];
+  olev *L = &W->rk[0].lev[l], *L1 = &W->rk[0].lev[0];
+  return s * (L->npx * L->npy) / (L1->npx * L1->npy);
+}
+
+static double compute_residual(oworld *W, int lev) {
+  int l = lev - 1;
+  double *loc = (double *)malloc(sizeof(double) * W->nranks);
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < W->nranks; r++) loc[r] = residual_local(&W->rk[r].lev[l], W->par.cmatrix_real);
+  fill_halo_all(W, l, f_r, HD(W->rk[0].lev[l].nz, 1, 0));
+  double res = sqrt(global_sum(W, l, loc));
+  free(loc);
+  return res;
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_intergrids.f90:16-72 fine2coarse, :139-162 fine2coarse_3D          */
+static void fine2coarse(oworld *W, int lev) {
+  int lf = lev - 1, lc = lev;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < W->nranks; r++) {
+    olev *F = &W->rk[r].lev[lf], *C = &W->rk[r].lev[lc];
+    int nx = C->gather ? C->nx / C->ngx : C->nx, ny = C->gather ? C->ny / C->ngy : C->ny, nz = C->nz;
+    double *y = C->gather ? C->dummy3 : C->b;
+    const double *x = F->r;
+    for (int i2 = 1; i2 <= nx; i2++) {
+      int i = 2 * i2 - 1;
+      for (int j2 = 1; j2 <= ny; j2++) {
+        int j = 2 * j2 - 1;
+        for (int k2 = 1; k2 <= nz; k2++) {
+          int k = 2 * k2 - 1;
+          double z = x[I3(F, k, j, i)] + x[I3(F, k, j, i + 1)] + x[I3(F, k, j + 1, i)] + x[I3(F, k, j + 1, i + 1)] +
+                     x[I3(F, k + 1, j, i)] + x[I3(F, k + 1, j, i + 1)] + x[I3(F, k + 1, j + 1, i)] +
+                     x[I3(F, k + 1, j + 1, i + 1)];
+          y[(((size_t)i2) * (ny + 2) + j2) * nz + (k2 - 1)] = z;
+        }
+      }
+    }
+  }
+  for (int r = 0; r < W->nranks; r++) {
+    olev *C = &W->rk[r].lev[lc];
+    if (C->gather) gather_into(W, r, lc, C->nz, -1, C->b);
+  }
+  fill_halo_all(W, lc, f_b, HD(W->rk[0].lev[lc].nz, 1, 0)); /* :68 */
+  for (int r = 0; r < W->nranks; r++) {                     /* :70 */
+    olev *C = &W->rk[r].lev[lc];
+    memset(C->p, 0, sizeof(double) * (size_t)C->nz * (C->ny + 2) * (C->nx + 2));
+  }
+}
+
+/* mg_intergrids.f90:167-228 coarse2fine, :366-450 linear, :336-363 nearest, mg_gather.f90:177-220 split */
+static void coarse2fine(oworld *W, int lev) {
+  int lf = lev - 1, lc = lev;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < W->nranks; r++) {
+    olev *F = &W->rk[r].lev[lf], *C = &W->rk[r].lev[lc];
+    int nx = C->nx, ny = C->ny, nz = C->nz;
+    const double *xc = C->p;
+    if (C->gather) { /* split: own quadrant incl. halo */
+      nx = C->nx / C->ngx; ny = C->ny / C->ngy;
+      int lq = C->key % 2, mq = C->key / 2;
+      for (int i = 0; i <= nx + 1; i++)
+        for (int j = 0; j <= ny + 1; j++)
+          for (int k = 1; k <= nz; k++)
+            C->dummy3[(((size_t)i) * (ny + 2) + j) * nz + (k - 1)] = C->p[I3(C, k, j + mq * ny, i + lq * nx)];
+      xc = C->dummy3;
+    }
+    double *xf = F->r;
+#define XC(k, j, i) xc[(((size_t)(i)) * (ny + 2) + (j)) * nz + ((k)-1)]
+#define XF(k, j, i) xf[I3(F, k, j, i)]
+    if (!W->par.interp_linear) {
+      for (int i2 = 1; i2 <= nx; i2++) { int i = 2 * i2 - 1;
+        for (int j2 = 1; j2 <= ny; j2++) { int j = 2 * j2 - 1;
+          for (int k2 = 1; k2 <= nz; k2++) { int k = 2 * k2 - 1; double v = XC(k2, j2, i2);
+            XF(k, j, i) = v; XF(k + 1, j, i) = v; XF(k, j + 1, i) = v; XF(k + 1, j + 1, i) = v;
+            XF(k, j, i + 1) = v; XF(k + 1, j, i + 1) = v; XF(k, j + 1, i + 1) = v; XF(k + 1, j + 1, i + 1) = v; } } }
+    } else {
+      const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
+      for (int i2 = 1; i2 <= nx; i2++) {
+        int i = 2 * i2 - 1;
+        for (int j2 = 1; j2 <= ny; j2++) {
+          int j = 2 * j2 - 1, k = 1, k2 = 1, kp;
+          XF(k, j, i) = +a * XC(k2, j2, i2) + c * XC(k2, j2 - 1, i2 - 1) + b * XC(k2, j2 - 1, i2) + b * XC(k2, j2, i2 - 1);
+          XF(k, j + 1, i) = +a * XC(k2, j2, i2) + c * XC(k2, j2 + 1, i2 - 1) + b * XC(k2, j2 + 1, i2) + b * XC(k2, j2, i2 - 1);
+          XF(k, j, i + 1) = +a * XC(k2, j2, i2) + c * XC(k2, j2 - 1, i2 + 1) + b * XC(k2, j2 - 1, i2) + b * XC(k2, j2, i2 + 1);
+          XF(k, j + 1, i + 1) = +a * XC(k2, j2, i2) + c * XC(k2, j2 + 1, i2 + 1) + b * XC(k2, j2 + 1, i2) + b * XC(k2, j2, i2 + 1);
+          for (k = 2; k <= nz * 2 - 1; k++) {
+            k2 = (k + 1) / 2;
+            kp = k2 - ((k % 2) * 2 - 1);
+            XF(k, j, i) = +d * XC(k2, j2, i2) + f * XC(k2, j2 - 1, i2 - 1) + e * XC(k2, j2 - 1, i2) + e * XC(k2, j2, i2 - 1) +
+                          e * XC(kp, j2, i2) + g * XC(kp, j2 - 1, i2 - 1) + f * XC(kp, j2 - 1, i2) + f * XC(kp, j2, i2 - 1);
+            XF(k, j + 1, i) = +d * XC(k2, j2, i2) + f * XC(k2, j2 + 1, i2 - 1) + e * XC(k2, j2 + 1, i2) + e * XC(k2, j2, i2 - 1) +
+                              e * XC(kp, j2, i2) + g * XC(kp, j2 + 1, i2 - 1) + f * XC(kp, j2 + 1, i2) + f * XC(kp, j2, i2 - 1);
+            XF(k, j, i + 1) = +d * XC(k2, j2, i2) + f * XC(k2, j2 - 1, i2 + 1) + e * XC(k2, j2 - 1, i2) + e * XC(k2, j2, i2 + 1) +
+                              e * XC(kp, j2, i2) + g * XC(kp, j2 - 1, i2 + 1) + f * XC(kp, j2 - 1, i2) + f * XC(kp, j2, i2 + 1);
+            XF(k, j + 1, i + 1) = +d * XC(k2, j2, i2) + f * XC(k2, j2 + 1, i2 + 1) + e * XC(k2, j2 + 1, i2) + e * XC(k2, j2, i2 + 1) +
+                                  e * XC(kp, j2, i2) + g * XC(kp, j2 + 1, i2 + 1) + f * XC(kp, j2 + 1, i2) + f * XC(kp, j2, i2 + 1);
+          }
+          k = nz * 2; /* k2 keeps its last value (= nz), mg_intergrids.f90:434 */
+          XF(k, j, i) = 0.5 * (a * XC(k2, j2, i2) + c * XC(k2, j2 - 1, i2 - 1) + b * XC(k2, j2 - 1, i2) + b * XC(k2, j2, i2 - 1));
+          XF(k, j + 1, i) = 0.5 * (a * XC(k2, j2, i2) + c * XC(k2, j2 + 1, i2 - 1) + b * XC(k2, j2 + 1, i2) + b * XC(k2, j2, i2 - 1));
+          XF(k, j, i + 1) = 0.5 * (a * XC(k2, j2, i2) + c * XC(k2, j2 - 1, i2 + 1) + b * XC(k2, j2 - 1, i2) + b * XC(k2, j2, i2 + 1));
+          XF(k, j + 1, i + 1) = 0.5 * (a * XC(k2, j2, i2) + c * XC(k2, j2 + 1, i2 + 1) + b * XC(k2, j2 + 1, i2) + b * XC(k2, j2, i2 + 1));
+        }
+      }
+    }
+#undef XC
+#undef XF
+  }
+  fill_halo_all(W, lf, f_r, HD(W->rk[0].lev[lf].nz, 1, 0)); /* :224 */
+  for (int r = 0; r < W->nranks; r++) {                     /* :226 whole array incl. halo */
+    olev *F = &W->rk[r].lev[lf];
+    size_t n = (size_t)F->nz * (F->ny + 2) * (F->nx + 2);
+    for (size_t q = 0; q < n; q++) F->p[q] = F->p[q] + F->r[q];
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_solvers.f90:129-151 Vcycle, :104-126 Fcycle, :17-101 solve_p       */
+static void vcycle(oworld *W, int lev1) {
+  for (int lev = lev1; lev <= W->nlevs - 1; lev++) {
+    relax_level(W, lev, W->par.ns_pre);
+    (void)compute_residual(W, lev);
+    fine2coarse(W, lev);
+  }
+  relax_level(W, W->nlevs, W->par.ns_coarsest);
+  for (int lev = W->nlevs - 1; lev >= lev1; lev--) {
+    coarse2fine(W, lev);
+    relax_level(W, lev, W->par.ns_post);
+  }
+}
+
+static void fcycle(oworld *W) {
+  for (int lev = 1; lev <= W->nlevs - 1; lev++) {
+    fine2coarse(W, lev);
+    for (int r = 0; r < W->nranks; r++) { /* grid(lev+1)%r = grid(lev+1)%b */
+      olev *C = &W->rk[r].lev[lev];
+      memcpy(C->r, C->b, sizeof(double) * (size_t)C->nz * (C->ny + 2) * (C->nx + 2));
+    }
+  }
+  relax_level(W, W->nlevs, W->par.ns_coarsest);
+  for (int lev = W->nlevs - 1; lev >= 1; lev--) {
+    coarse2fine(W, lev);
+    vcycle(W, lev);
+  }
+}
+
+/* hist[0] = rnorm0, hist[n] = normalised residual after iteration n */
+static int solve_p(oworld *W, double tol, int maxite, double *hist, double *bnorm_out) {
+  double *loc = (double *)malloc(sizeof(double) * W->nranks);
+  for (int r = 0; r < W->nranks; r++) {
+    olev *L = &W->rk[r].lev[0];
+    memset(L->p, 0, sizeof(double) * (size_t)L->nz * (L->ny + 2) * (L->nx + 2));
+    double s = 0.0; /* sum(b(1:nz,1:ny,1:nx)**2), array order */
+    for (int i = 1; i <= L->nx; i++) for (int j = 1; j <= L->ny; j++) for (int k = 1; k <= L->nz; k++) {
+      double v = L->b[I3(L, k, j, i)]; s += v * v; }
+    loc[r] = s;
+  }
+  double bnorm = sqrt(global_sum(W, 0, loc));
+  free(loc);
+  if (bnorm_out) *bnorm_out = bnorm;
+  int nite = 0;
+  double rnorm = compute_residual(W, 1);
+  double res0 = rnorm / bnorm;
+  if (hist) hist[0] = res0;
+  while (nite < maxite && res0 > tol) {
+    fcycle(W);
+    rnorm = compute_residual(W, 1);
+    rnorm = rnorm / bnorm;
+    res0 = rnorm;
+    nite++;
+    if (hist) hist[nite] = rnorm;
+  }
+  return nite;
+}
+
+/* ------------------------------------------------------------------ */
+/* mg_compute_rhs.f90:14-379 compute_rhs (bmask=.false.)                */
+static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
+  const double two = 2.0, hlf = 0.5, qrt = 0.25;
+  int nzg = W->rk[0].lev[0].nz;
+  for (int pass = 0; pass < 3; pass++) {
+    for (int r = 0; r < W->nranks; r++) {
+      orank *R = &W->rk[r];
+      olev *L = &R->lev[0];
+      int nx = L->nx, ny = L->ny, nz = L->nz;
+      const double *rm = rmask_by_rank ? rmask_by_rank[r] : NULL;
+#define RM(j, i) (rm ? rm[I2(L, j, i)] : 1.0)
+#define U(i, j, k) R->u[(((size_t)((k)-1)) * (ny + 2) + (j)) * (nx + 1) + ((i)-1)]
+#define V(i, j, k) R->v[(((size_t)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
+#define Wv(i, j, k) R->w[(((size_t)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
+#define ZW(k, j, i) L->zw[IZW(L, k, j, i)]
+#define DX(j, i) L->dx[I2(L, j, i)]
+#define DY(j, i) L->dy[I2(L, j, i)]
+#define CW(k, j, i) L->cw[I3P(L, k, j, i)]
+#define DZW(k, j, i) L->dzw[I3P(L, k, j, i)]
+#define ZXDY(k, j, i) L->zxdy[I3(L, k, j, i)]
+#define ZYDX(k, j, i) L->zydx[I3(L, k, j, i)]
+#define UF(k, j, i) R->dum_nz[I3(L, k, j, i)]
+#define WF(k, j, i) R->dum_nzp[I3P(L, k, j, i)]
+#define RHS(k, j, i) L->b[I3(L, k, j, i)]
+      if (pass == 0) {
+        memset(L->b, 0, sizeof(double) * (size_t)nz * (ny + 2) * (nx + 2)); /* :91 */
+        int k = 1;
+        for (int i = 1; i <= nx + 1; i++)
+          for (int j = 1; j <= ny; j++)
+            UF(k, j, i) =
+                (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+                 - qrt * (+ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                          ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))
+                 - (+ZXDY(k, j, i) * ZXDY(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
+                    ZXDY(k, j, i - 1) * ZXDY(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1))) *
+                       (hlf * (DX(j, i) + DX(j, i - 1))) * U(i, j, k)
+                 - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
+                        (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0) +
+                    ZXDY(k, j, i - 1) * ZYDX(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * hlf *
+                        (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * 1.0 +
+                         hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * 1.0))) * 1.0;
+        for (int i = 1; i <= nx + 1; i++)
+          for (int j = 1; j <= ny; j++)
+            for (k = 2; k <= nz - 1; k++)
+              UF(k, j, i) =
+                  (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+                   - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                            ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                            ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
+                            ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+        k = nz;
+        for (int i = 1; i <= nx + 1; i++)
+          for (int j = 1; j <= ny; j++)
+            UF(k, j, i) =
+                (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+                 - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                          ZXDY(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                          ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
+                          ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+      } else if (pass == 1) {
+        for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (int k = 1; k <= nz; k++)
+          RHS(k, j, i) = UF(k, j, i + 1) - UF(k, j, i); /* :178-186 */
+        /* VF :195-269, stored in the same dummy array */
+        int k = 1;
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny + 1; j++)
+            UF(k, j, i) =
+                (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+                 - qrt * (+ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                          ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))
+                 - (+ZYDX(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
+                    ZYDX(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i))) *
+                       hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k)
+                 - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
+                        (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0) +
+                    ZXDY(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * hlf *
+                        (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * 1.0 +
+                         hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * 1.0))) * 1.0;
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny + 1; j++)
+            for (k = 2; k <= nz - 1; k++)
+              UF(k, j, i) =
+                  (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+                   - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                            ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                            ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
+                            ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+        k = nz;
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny + 1; j++)
+            UF(k, j, i) =
+                (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+                 - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                          ZYDX(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                          ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
+                          ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+      } else {
+        for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (int k = 1; k <= nz; k++)
+          RHS(k, j, i) = RHS(k, j, i) + UF(k, j + 1, i) - UF(k, j, i); /* :279-287 */
+        /* WF :296-356 */
+        for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) WF(1, j, i) = 0.0;
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny; j++)
+            for (int k = 2; k <= nz; k++)
+              WF(k, j, i) = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
+                            qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 +
+                                         ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0 +
+                                         ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
+                                         ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0);
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny; j++)
+            for (int k = 2; k <= nz; k++)
+              WF(k, j, i) = WF(k, j, i) -
+                            qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 +
+                                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0 +
+                                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
+                                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+        int k = nz + 1;
+        for (int i = 1; i <= nx; i++)
+          for (int j = 1; j <= ny; j++)
+            WF(k, j, i) = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
+                          hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
+                                       ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0) -
+                          hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
+                                       ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+        for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (k = 1; k <= nz; k++)
+          RHS(k, j, i) = RHS(k, j, i) + WF(k + 1, j, i) - WF(k, j, i); /* :362-370 */
+      }
+    }
+    /* fill_halo(1,uf,lbc_null='u') :171 / fill_halo(1,vf,lbc_null='v') :272 */
+    if (pass < 2) {
+      halo_desc d = HD(nzg, 1, pass == 0 ? 'u' : 'v');
+      for (int r = 0; r < W->nranks; r++) halo_phase1(&W->rk[r].lev[0], W->rk[r].dum_nz, &d);
+      /* phase 2 needs a field accessor: park the per-rank pointers in dummy3 of level 1 */
+      for (int r = 0; r < W->nranks; r++) W->rk[r].lev[0].dummy3 = W->rk[r].dum_nz;
+      for (int r = 0; r < W->nranks; r++) halo_phase2(W, r, 0, f_dummy3, &d);
+      for (int r = 0; r < W->nranks; r++) W->rk[r].lev[0].dummy3 = NULL;
+    }
+  }
+#undef RM
+#undef V
+#undef Wv
+#undef ZW
+#undef DX
+#undef DY
+#undef CW
+#undef DZW
+#undef ZXDY
+#undef ZYDX
+#undef UF
+#undef WF
+#undef RHS
+}
+
+/* mg_correct_uvw.f90:15-115 correct_uvw (bmask=.false.) */
+static void correct_uvw(oworld *W) {
+  const double one = 1.0, hlf = 0.5;
+  for (int r = 0; r < W->nranks; r++) {
+    orank *R = &W->rk[r];
+    olev *L = &R->lev[0];
+    int nx = L->nx, ny = L->ny, nz = L->nz;
+#define Wv(i, j, k) R->w[(((size_t)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
+#define V(i, j, k) R->v[(((size_t)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
+#define P(k, j, i) L->p[I3(L, k, j, i)]
+    for (int i = 1; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
+      double dxu = hlf * (L->dx[I2(L, j, i)] + L->dx[I2(L, j, i - 1)]);
+      U(i, j, k) = U(i, j, k) - one / dxu * (P(k, j, i) - P(k, j, i - 1)) * 1.0;
+    }
+    for (int i = 0; i <= nx + 1; i++) for (int j = 1; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
+      double dyv = hlf * (L->dy[I2(L, j, i)] + L->dy[I2(L, j - 1, i)]);
+      V(i, j, k) = V(i, j, k) - one / dyv * (P(k, j, i) - P(k, j - 1, i)) * 1.0;
+    }
+    for (int i = 0; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) {
+      for (int k = 2; k <= nz; k++) {
+        double dzw = L->zr[IZR(L, k, j, i)] - L->zr[IZR(L, k - 1, j, i)];
+        Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (P(k, j, i) - P(k - 1, j, i));
+      }
+      int k = nz + 1;
+      double dzw = L->zw[IZW(L, nz + 1, j, i)] - L->zr[IZR(L, nz, j, i)];
+      Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (-P(k - 1, j, i));
+    }
+#undef Wv
+#undef V
+#undef P
+  }
+}
+#undef U
+
+/* ================================================================== */
+/* public API (ctypes)                                                  */
+void *mgo_create(int nxl, int nyl, int nzl, int npx, int npy, const mgo_params *par) {
+  oworld *W = (oworld *)calloc(1, sizeof(oworld));
+  W->par = *par;
+  W->npx = npx; W->npy = npy; W->nranks = npx * npy;
+  W->nlevs = find_grid_levels(npx, npy, nxl, nyl, nzl);
+  W->rk = (orank *)calloc(W->nranks, sizeof(orank));
+  for (int r = 0; r < W->nranks; r++) {
+    orank *R = &W->rk[r];
+    R->rank = r; R->pj = r / npx; R->pi = r % npx; /* mg_grids.f90:593-594 */
+    R->lev = (olev *)calloc(W->nlevs, sizeof(olev));
+    define_grid_dims(W, R, nxl, nyl, nzl);
+    define_neighbours(W, R);
+    for (int l = 0; l < W->nlevs; l++) {
+      olev *L = &R->lev[l];
+      size_t n2 = (size_t)(L->ny + 2) * (L->nx + 2), n3 = n2 * L->nz;
+      L->cA = dalloc(n3 * 8); L->p = dalloc(n3); L->b = dalloc(n3); L->r = dalloc(n3);
+      L->dx = dalloc(n2); L->dy = dalloc(n2); L->zeta = dalloc(n2); L->h = dalloc(n2);
+      L->zr = dalloc((size_t)(L->ny + 4) * (L->nx + 4) * L->nz);
+      L->zw = dalloc((size_t)(L->ny + 4) * (L->nx + 4) * (L->nz + 1));
+      L->cw = dalloc(n2 * (L->nz + 1));
+      if (l == 0) { L->dzw = dalloc(n2 * (L->nz + 1)); L->zxdy = dalloc(n3); L->zydx = dalloc(n3); }
+    }
+    define_gather_informations(W, R);
+    olev *L = &R->lev[0];
+    R->u = dalloc((size_t)(L->nx + 1) * (L->ny + 2) * L->nz);
+    R->v = dalloc((size_t)(L->nx + 2) * (L->ny + 1) * L->nz);
+    R->w = dalloc((size_t)(L->nx + 2) * (L->ny + 2) * (L->nz + 1));
+    R->dum_nz = dalloc((size_t)(L->ny + 2) * (L->nx + 2) * L->nz);
+    R->dum_nzp = dalloc((size_t)(L->ny + 2) * (L->nx + 2) * (L->nz + 1));
+  }
+  return W;
+}
+
+void mgo_destroy(void *h) {
+  oworld *W = (oworld *)h;
+  for (int r = 0; r < W->nranks; r++) {
+    orank *R = &W->rk[r];
+    for (int l = 0; l < W->nlevs; l++) {
+      olev *L = &R->lev[l];
+      free(L->cA); free(L->p); free(L->b); free(L->r); free(L->dx); free(L->dy); free(L->zeta); free(L->h);
+      free(L->zr); free(L->zw); free(L->cw); free(L->dzw); free(L->zxdy); free(L->zydx);
+      if (l > 0) { free(L->dummy3); for (int q = 0; q < 4; q++) free(L->tmp2[q]); }
+    }
+    free(R->lev); free(R->u); free(R->v); free(R->w); free(R->dum_nz); free(R->dum_nzp);
+  }
+  free(W->rk); free(W);
+}
+
+int mgo_nlevs(void *h) { return ((oworld *)h)->nlevs; }
+
+/* out[0..11] = nx,ny,nz,npx,npy,incx,incy,gather,ngx,ngy,key,color ; out[12..19] = neighbours */
+void mgo_level_info(void *h, int rank, int lev, int *out) {
+  olev *L = &((oworld *)h)->rk[rank].lev[lev - 1];
+  int v[12] = {L->nx, L->ny, L->nz, L->npx, L->npy, L->incx, L->incy, L->gather, L->ngx, L->ngy, L->key, L->color};
+  memcpy(out, v, sizeof(v));
+  memcpy(out + 12, L->neighb, sizeof(int) * 8);
+}
+
+/* field ids: 0 p,1 b,2 r,3 cA,4 dx,5 dy,6 zeta,7 h,8 zr,9 zw,10 cw,11 u,12 v,13 w */
+double *mgo_field(void *h, int rank, int lev, int id) {
+  orank *R = &((oworld *)h)->rk[rank];
+  olev *L = &R->lev[lev - 1];
+  switch (id) {
+    case 0: return L->p; case 1: return L->b; case 2: return L->r; case 3: return L->cA;
+    case 4: return L->dx; case 5: return L->dy; case 6: return L->zeta; case 7: return L->h;
+    case 8: return L->zr; case 9: return L->zw; case 10: return L->cw;
+    case 11: return R->u; case 12: return R->v; case 13: return R->w;
+  }
+  return NULL;
+}
+
+/* nhydro.f90:36-50 nhydro_matrices: geometry must have been written into level-1 dx,dy,zeta,h of every rank */
+void mgo_matrices(void *h, double hc, double theta_b, double theta_s) {
+  oworld *W = (oworld *)h;
+  W->hlim = hc; W->theta_b = theta_b; W->theta_s = theta_s;
+  define_matrices(W);
+}
+
+void mgo_compute_rhs(void *h) { compute_rhs((oworld *)h, NULL); }
+void mgo_correct_uvw(void *h) { correct_uvw((oworld *)h); }
+int mgo_solve_p(void *h, double tol, int maxite, double *hist, double *bnorm) { return solve_p((oworld *)h, tol, maxite, hist, bnorm); }
+void mgo_fcycle(void *h) { fcycle((oworld *)h); }
+void mgo_vcycle(void *h, int lev) { vcycle((oworld *)h, lev); }
+void mgo_relax(void *h, int lev, int nsweeps) { relax_level((oworld *)h, lev, nsweeps); }
+double mgo_residual(void *h, int lev) { return compute_residual((oworld *)h, lev); }
+void mgo_fine2coarse(void *h, int lev) { fine2coarse((oworld *)h, lev); }
+void mgo_coarse2fine(void *h, int lev) { coarse2fine((oworld *)h, lev); }
+void mgo_fill_halo(void *h, int lev, int id) {
+  oworld *W = (oworld *)h;
+  field_fn f = id == 0 ? f_p : (id == 1 ? f_b : f_r);
+  fill_halo_all(W, lev - 1, f, HD(W->rk[0].lev[lev - 1].nz, 1, 0));
+}
+
+/* nhydro.f90:53-102 nhydro_solve: returns iteration count */
+int mgo_nhydro_solve(void *h, double *hist, double *bnorm) {
+  oworld *W = (oworld *)h;
+  compute_rhs(W, NULL);
+  int n = solve_p(W, W->par.solver_prec, W->par.solver_maxiter, hist, bnorm);
+  correct_uvw(W);
+  return n;
+}
+/* nhydro.f90:105-134 */
+void mgo_check_nondivergence(void *h) { compute_rhs((oworld *)h, NULL); }
