@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: multigrid V-cycles per second of the pressure solve on the seamount 512x512x64 problem
+(BASELINE.json `metric`, configs[2]: the configuration the metric is quoted on; it fits one GPU), plus the
+HBM roofline fraction of the level-1 smoother kernel and the CPU baseline (oracle) timed on the host cores.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one Vcycle(1) (mg_solvers.f90:129) over the resident fields: ns_pre=3 sweeps + residual + restriction on
+every level down, 40 sweeps on the coarsest, prolongation + ns_post=2 sweeps up.  Inputs are synthetic (the
+reference's seamount geometry, u=v=0, w=-1) and resident in HBM before the timed region.  Weak scaling: every rank
+owns a 512x512x64 block; `value` is V-cycles/s scaled by (global cells / cells of one block), i.e. block-V-cycles/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+SMOOTHER_BYTES_PER_CELL = 88  # cA 64 + b 8 + p read 8 + p write 8, per cell per full sweep
+PGRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+
+
+def cpu_baseline(nx, ny, nz, method, cycles=2):
+    """The oracle (CPU restatement of the reference, oracle/mgoracle.c) on the same workload, decomposed over the
+    host cores like the reference's MPI ranks (one OpenMP thread per emulated rank)."""
+    from oracle.mgoracle import make_seamount
+    ncpu = os.cpu_count() or 1
+    cores = 1
+    while cores * 2 <= min(ncpu, 16):
+        cores *= 2
+    npx, npy = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2), 16: (4, 4)}[cores]
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    o = make_seamount(nx // npx, ny // npy, nz, npx, npy, relax_method=method)
+    o.compute_rhs()
+    o.vcycle(1)  # untimed: first touch
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        o.vcycle(1)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    o.relax(1, 1)
+    sweep = time.perf_counter() - t1
+    o.close()
+    return {"value": cycles / dt, "unit": "Vcycle(1)/s", "cores": cores, "kind": "port",
+            "sample": f"{cycles} Vcycle(1) of seamount {nx}x{ny}x{nz} {method} on {npx}x{npy} emulated ranks "
+                      f"({cores} OpenMP threads), after 1 untimed cycle",
+            "level1_sweep_ms": sweep * 1e3,
+            "level1_sweep_GBs": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / sweep / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, nargs=3, default=[512, 512, 64], help="local block nx ny nz")
+    ap.add_argument("--method", default="FC", choices=["FC", "RB"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.gpus not in PGRID:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from mgroms_amd.parallel import Comm
+        comm = Comm()
+
+    import mgroms_amd as mg
+    from mgroms_amd import nhydro
+    from oracle.mgoracle import seamount_geometry  # synthetic-input generator only (mg_setup_tests.f90:145)
+
+    nx, ny, nz = args.size
+    npx, npy = PGRID[args.gpus]
+    nhydro.set_verbose(0)
+    par = nhydro.default_params(relax_method=args.method)
+    mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
+    dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
+    mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+    u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
+    nhydro.compute_rhs(u, v, w)
+    res0 = mg.compute_residual(1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mg.Vcycle(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mg.Vcycle(1)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res1 = mg.compute_residual(1)
+
+    # roofline of the dominant kernel: the level-1 smoother sweep (HIP events on the solver's stream)
+    sweep_ms = nhydro.time_relax(1, args.sweep_reps)
+    resid_ms = nhydro.time_residual(1, args.sweep_reps)
+    ncol = 4 if args.method == "FC" else 2
+    cells = nx * ny * nz
+    launch_bytes = SMOOTHER_BYTES_PER_CELL * cells / ncol
+    achieved = launch_bytes / (sweep_ms / ncol * 1e-3) / 1e9
+    # F-cycle iteration rate (solve_p iteration = Fcycle + residual), for reference
+    sync()
+    t2 = time.perf_counter()
+    nf = max(2, args.steps // 4)
+    for _ in range(nf):
+        mg.Fcycle()
+        mg.compute_residual(1)
+    sync()
+    fc_rate = nf / (time.perf_counter() - t2)
+
+    out = None
+    if rank == 0:
+        scale = npx * npy
+        out = {
+            "metric": "vcycles_per_sec", "value": args.steps / dt * scale, "unit": "Vcycle(1)/s per 512x512x64 block-equivalent",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"seamount {nx * npx}x{ny * npy}x{nz} ({npx}x{npy} ranks of {nx}x{ny}x{nz}), "
+                                   f"relax_method={args.method}, ns_pre=3 ns_post=2 ns_coarsest=40, cmatrix=real, interp=linear",
+                       "levels": mg.nlevs(), "step": "one Vcycle(1)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_relax_colour (level 1, one colour pass)",
+                         "algorithmic_bytes_per_launch": launch_bytes,
+                         "launch_ms": sweep_ms / ncol, "sweep_ms": sweep_ms},
+            "residual_kernel": {"ms": resid_ms, "GBs": 88 * cells / (resid_ms * 1e-3) / 1e9},
+            "fcycle_iterations_per_sec": fc_rate,
+            "residual_before": res0, "residual_after": res1,
+            "counters": nhydro.counters(),
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, nz, args.method)
+        else:
+            out["cpu_baseline"] = None
+    mg.nhydro_clean()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/*
+ * mgx.h -- C ABI of the MI355X-native multigrid pressure solver (libmgx.so).
+ *
+ * Drop-in boundary for the hot path of CESR-lab/mgroms: every entry point below
+ * replaces one Fortran module procedure of the reference (file:line relative to
+ * the reference's src/).  The reference has no C interop; a Fortran module
+ * `nhydro` with the reference's five signatures forwards to these through
+ * ISO_C_BINDING (fortran/nhydro.f90).  Like the reference
+ * (module-global `grid(:)`, mg_grids.f90:113-117) the library holds ONE solver
+ * instance per process; one process drives one GPU.
+ *
+ * Conventions
+ *  - all arrays are host pointers to double (real(kind=8)); the library owns
+ *    every device array until mgx_clean().
+ *  - 2-D geometry arrays are (0:ny+1, 0:nx+1), j fastest (mg_define_matrix.f90:71-76).
+ *  - 3-D solver fields are (nz, 0:ny+1, 0:nx+1), k fastest (mg_grids.f90:207-209);
+ *    cA is (8, nz, 0:ny+1, 0:nx+1) (mg_grids.f90:221).
+ *  - model velocities are (i,j,k)-ordered, i fastest (nhydro.f90:57-59):
+ *    u(1:nx+1,0:ny+1,1:nz)  v(0:nx+1,1:ny+1,1:nz)  w(0:nx+1,0:ny+1,0:nz).
+ *  - every function returns 0 on success; on failure a non-zero code, and
+ *    mgx_last_error() describes it (the reference would `stop -1`).
+ */
+#ifndef MGX_API_H_INCLUDED
+#define MGX_API_H_INCLUDED
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The 13 members of namelist /nhparam/ (mg_namelist.f90:37-50), defaults :11-35 */
+typedef struct mgx_params {
+  double solver_prec;     /* 1e-6 */
+  int solver_maxiter;     /* 50 */
+  int nsmall;             /* 8 */
+  int ns_coarsest;        /* 40 */
+  int ns_pre;             /* 3 */
+  int ns_post;            /* 2 */
+  char cmatrix[16];       /* 'real' | 'simple' */
+  char relax_method[16];  /* 'Gauss-Seidel','GS' | 'Red-Black','RB' | 'Four-Color','FC' */
+  char interp_type[16];   /* 'linear' | 'nearest' */
+  char restrict_type[16]; /* 'avg' (never read by the reference outside the namelist) */
+  int aggressive;         /* .false. ; .true. is rejected (unimplemented in the reference, mg_intergrids.f90:243) */
+  int netcdf_output;      /* .false. ; ignored (debug I/O, out of scope) */
+  int bmask;              /* .false. ; .true. is rejected this round */
+} mgx_params;
+
+/* field ids for mgx_get_field / mgx_set_field / mgx_fill_halo */
+enum { MGX_P = 0, MGX_B = 1, MGX_R = 2, MGX_CA = 3, MGX_DX = 4, MGX_DY = 5, MGX_ZETA = 6, MGX_H = 7,
+       MGX_ZR = 8, MGX_ZW = 9, MGX_CW = 10 };
+
+/* fills *p with the defaults of mg_namelist.f90:11-35 */
+int mgx_params_default(mgx_params *p);
+/* read_nhnamelist (mg_namelist.f90:55-127): parse &nhparam from `path` (NULL = "nh_namelist");
+ * a missing file keeps *p unchanged; linear+linear is rejected (:95-98). */
+int mgx_read_namelist(const char *path, mgx_params *p);
+
+/* nhydro_init(nx,ny,nz,npxg,npyg) (nhydro.f90:18-33).  nx,ny,nz: local block; npx,npy: process grid;
+ * rank: this process's rank, placed at pi=mod(rank,npx), pj=rank/npx (mg_grids.f90:593-594).
+ * par == NULL: read ./nh_namelist if present, else defaults (what the reference does). */
+int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par);
+/* nhydro_matrices(dx,dy,zeta,h,rmask,hc,theta_b,theta_s) (nhydro.f90:36-50) -> define_matrices
+ * (mg_define_matrix.f90:28-208).  rmask may be NULL (= all ones; only read when bmask). */
+int mgx_matrices(const double *dx, const double *dy, const double *zeta, const double *h, const double *rmask,
+                 double hc, double theta_b, double theta_s);
+/* nhydro_solve(nx,ny,nz,rmask,u,v,w) (nhydro.f90:53-102): compute_rhs, solve_p, correct_uvw; u,v,w updated in place */
+int mgx_solve(double *u, double *v, double *w, const double *rmask);
+/* nhydro_check_nondivergence (nhydro.f90:105-134): recompute the divergence into grid(1)%b */
+int mgx_check_nondivergence(double *u, double *v, double *w, const double *rmask);
+/* nhydro_clean (nhydro.f90:137-141) */
+void mgx_clean(void);
+
+/* mg_solvers.f90:17-101 solve_p(tol,maxite).  *nite = iterations done, *res = last ||r||/||b||,
+ * hist (may be NULL, else >= maxite+1 doubles) = normalised residual after each iteration, hist[0] = initial. */
+int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist);
+int mgx_fcycle(void);                     /* mg_solvers.f90:104-126 */
+int mgx_vcycle(int lev);                  /* mg_solvers.f90:129-151 */
+int mgx_relax(int lev, int nsweeps);      /* mg_relax.f90:16-47   */
+int mgx_residual(int lev, double *res);   /* mg_relax.f90:337-383: r = b - A p, halo fill of r, *res = global ||r||_2 */
+int mgx_fine2coarse(int lev);             /* mg_intergrids.f90:16-72  */
+int mgx_coarse2fine(int lev);             /* mg_intergrids.f90:167-228 */
+int mgx_fill_halo(int lev, int field);    /* mg_mpi_exchange.f90:396-745 (p,b,r) */
+/* compute_rhs / correct_uvw on the device-resident model state (mg_compute_rhs.f90:14, mg_correct_uvw.f90:15) */
+int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask);
+
+/* grid(lev)%<field> accessors (mg_grids.f90:24-65), host layout as described above */
+int mgx_nlevs(void);
+int mgx_level_dims(int lev, int *nx, int *ny, int *nz);
+/* out[0..9] = npx,npy,incx,incy,gather,ngx,ngy,key,color,0 ; out[10..17] = neighbours S,E,N,W,SW,SE,NE,NW (-1 = none) */
+int mgx_level_info(int lev, int *out);
+int mgx_get_field(int lev, int field, double *host);
+int mgx_set_field(int lev, int field, const double *host);
+
+/* ---- multi-rank plumbing (replaces MPI in mg_mpi_exchange.f90 / mg_gather.f90) ----
+ * The data path stays on the GPU: the library packs edges into device buffers and asks the host layer
+ * (torch.distributed over RCCL) to move them.  All pointers handed to the callbacks are DEVICE pointers.
+ *  exchange : for q in 0..n-1 send sendbuf[q] (count[q] doubles) to peer[q] and receive recvbuf[q]
+ *             (count[q] doubles) from the same peer                           (fill_halo_*, :504-718)
+ *  allreduce: in-place sum of n doubles over all ranks                          (global_sum, :1555-1571)
+ *  allgather: gather `count` doubles from each of the `ng` ranks in `group` (ordered as the reference's
+ *             localcomm, mg_grids.f90:702-718) into recvbuf                     (gather_3D, mg_gather.f90:126)
+ * Each returns 0 on success.  Work must be enqueued on / ordered with the stream given to mgx_set_stream. */
+typedef int (*mgx_exchange_fn)(void *ctx, int n, const int *peer, double *const *sendbuf, double *const *recvbuf,
+                               const int *count);
+typedef int (*mgx_allreduce_fn)(void *ctx, double *devbuf, int n);
+typedef int (*mgx_allgather_fn)(void *ctx, const int *group, int ng, const double *sendbuf, double *recvbuf, int count);
+int mgx_set_comm(mgx_exchange_fn ex, mgx_allreduce_fn ar, mgx_allgather_fn ag, void *ctx);
+
+/* HIP stream (hipStream_t) every kernel is launched on; NULL = the default stream */
+int mgx_set_stream(void *hip_stream);
+/* 0 = silent, 1 = the reference's rank-0 prints (parameter block, level table, "ite = ..: res = .. / conv = ..") */
+int mgx_set_verbose(int level);
+
+/* ---- measurement helpers used by bench.py (timed with HIP events on the solver's stream) ---- */
+/* run `reps` smoother sweeps on level `lev` (reps x relax(lev,1)); *ms = average milliseconds per sweep */
+int mgx_time_relax(int lev, int reps, float *ms);
+int mgx_time_residual(int lev, int reps, float *ms);
+/* counters since mgx_init: out[0]=kernel launches, out[1]=halo fills, out[2]=exchanges, out[3]=allreduces */
+int mgx_counters(long long *out);
+
+const char *mgx_last_error(void);
+const char *mgx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

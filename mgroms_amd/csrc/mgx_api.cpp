@@ -1,0 +1,830 @@
+// Host side of libmgx.so: solver state, level hierarchy, halo / gather plumbing, cycle control and the
+// C ABI declared in include/mgx.h.  Mirrors the reference's module structure:
+//   mg_grids.f90 (levels, neighbours, gather groups)      -> define_levels()
+//   mg_define_matrix.f90 (define_matrices_topo)           -> define_matrices()
+//   mg_mpi_exchange.f90 (fill_halo_*, global_sum)         -> fill_halo_js(), rl_fill_halo(), global_sum()
+//   mg_gather.f90 (gather, split)                         -> inside fine2coarse()/coarse2fine()
+//   mg_relax.f90 / mg_intergrids.f90 / mg_solvers.f90     -> relax(), residual(), fine2coarse(), ...
+// There is no CPU compute path: every operator is a HIP kernel launch (mgx_kernels.hip, mgx_setup.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mgx.h"
+#include "mgx_internal.h"
+
+struct RectOp { int op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, mi2, ci2; };
+struct ModelView { double *u, *v, *w, *rmask; };
+
+extern "C" {
+void mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int);
+void mgxk_snapshot_k1(hipStream_t, const LevView *);
+int mgxk_residual_nblocks(const LevView *);
+void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int);
+void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
+void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *);
+void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int);
+void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
+void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
+void mgxk_halo_pack(hipStream_t, const LevView *, double *, double *, int, int);
+void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
+void mgxk_gather_place(hipStream_t, const LevView *, double *, const double *, int, int, int, int);
+void mgxk_block_to_ref(hipStream_t, const LevView *, const double *, double *);
+void mgxk_split(hipStream_t, const LevView *, const LevView *, const double *, double *, int, int);
+void mgxs_coarsen2d(hipStream_t, const double *, double *, int, int, int, double);
+void mgxs_rect(hipStream_t, double *, double *, const RectOp *);
+void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
+void mgxs_define_matrix(hipStream_t, const GeoView *, int);
+void mgxs_pivots(hipStream_t, const LevView *);
+void mgxs_rhs_uf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxs_rhs_vf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxs_rhs_wf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxs_rhs_accum(hipStream_t, const GeoView *, const LevView *, const double *, int);
+void mgxs_correct_uvw(hipStream_t, const GeoView *, const LevView *, const ModelView *);
+}
+
+namespace {
+
+enum { M_GS = 0, M_RB = 1, M_FC = 2 };
+
+struct Level {
+  int nx, ny, nz, npx, npy, incx, incy, gather, ngx, ngy, key, color;
+  int neighb[8];
+  LevView v;    // solver fields (JS)
+  LevView vs;   // pre-gather / split block (gathered levels): vs.b = restricted block, vs.p = split block
+  GeoView g;    // set-up arrays (reference layout)
+  double *tmp2[4];  // pre-gather coarse dx,dy,zeta,h
+  double *blk, *gbuf;  // all-gather send / receive (reference layout blocks incl. halo)
+  int group[4], ngroup;
+  size_t n3js;  // doubles in one JS array
+};
+
+struct State {
+  bool inited = false, have_matrix = false;
+  mgx_params par;
+  int method = M_RB, real = 1, linear = 1;
+  int nlevs = 0, npx = 1, npy = 1, nranks = 1, rank = 0, pi = 0, pj = 0;
+  std::vector<Level> lev;
+  double hlim = 0, theta_b = 0, theta_s = 0;
+  hipStream_t stream = nullptr;
+  mgx_exchange_fn ex = nullptr; mgx_allreduce_fn ar = nullptr; mgx_allgather_fn ag = nullptr; void *ctx = nullptr;
+  double *d_partial = nullptr; int npartial = 0;
+  double *d_scalar = nullptr; double *h_scalar = nullptr;
+  double *ref_scratch = nullptr; size_t ref_scratch_n = 0;  // reference-layout staging (8 x level-1 field)
+  double *xbuf[16]; size_t xbuf_n = 0;                       // 8 send + 8 receive halo buffers
+  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
+  std::vector<void *> allocs;
+  int verbose = 1;
+  long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
+  std::string err;
+};
+
+State S;
+
+int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  S.err = buf;
+  if (S.verbose) fprintf(stderr, "mgx error: %s\n", buf);
+  return 1;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define CHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+#define NEED_INIT() do { if (!S.inited) return fail("mgx_init has not been called"); } while (0)
+#define NEED_LEV(l) do { NEED_INIT(); if ((l) < 1 || (l) > S.nlevs) return fail("level %d out of range 1..%d", (l), S.nlevs); } while (0)
+
+int dmalloc(double **p, size_t n) {
+  void *q = nullptr;
+  HIPCHK(hipMalloc(&q, (n ? n : 1) * sizeof(double)));
+  HIPCHK(hipMemsetAsync(q, 0, (n ? n : 1) * sizeof(double), S.stream));
+  S.allocs.push_back(q);
+  *p = (double *)q;
+  return 0;
+}
+
+int roundup(int a, int m) { return (a + m - 1) / m * m; }
+
+void make_view(LevView &v, int nx, int ny, int nz) {
+  v.nx = nx; v.ny = ny; v.nz = nz;
+  v.EO = 15;
+  v.HO = roundup(16 + ny / 2, 16);
+  v.RS = roundup(v.HO + ny / 2 + 1, 16);
+  v.plane = (long long)nz * v.RS;
+}
+
+// ---- mg_grids.f90:468-738 -------------------------------------------------------------------------
+int find_grid_levels(int npxg, int npyg, int nx, int ny, int nz) {
+  const int nxg = npxg * nx, nyg = npyg * ny, nzg = nz, ncoarsest = 4, nzmin = 2;
+  const int nhoriz = nxg < nyg ? nxg : nyg;
+  const int nl1 = 1 + (int)floor(log(nhoriz * 1.0 / ncoarsest * 1.0) / log(2.0));
+  const int nl2 = 1 + (int)floor(log(nzg * 1.0 / nzmin * 1.0) / log(2.0));
+  return nl1 < nl2 ? nl1 : nl2;
+}
+
+// level table of an arbitrary rank (needed to form gather groups without communication)
+void rank_level_table(int rank, std::vector<Level> &T) {
+  const int npx0 = S.npx, npy0 = S.npy, pi = rank % npx0, pj = rank / npx0;
+  int nx = T[0].nx, ny = T[0].ny, nz = T[0].nz, npx = npx0, npy = npy0, incx = 1, incy = 1;
+  T[0].npx = npx; T[0].npy = npy; T[0].incx = 1; T[0].incy = 1; T[0].gather = 0; T[0].ngx = 1; T[0].ngy = 1; T[0].key = 0; T[0].color = 0;
+  for (int l = 1; l < (int)T.size(); l++) {  // define_grid_dims :503-577
+    Level &L = T[l];
+    if (nz == 1) { nx /= 2; ny /= 2; } else { nx /= 2; ny /= 2; nz /= 2; }
+    L.gather = 0; L.ngx = 1; L.ngy = 1; L.key = 0; L.color = 0;
+    if (((nx < ny ? nx : ny) < S.par.nsmall) && (npx * npy > 1)) {
+      L.gather = 1;
+      if (npx > 1) { npx /= 2; nx *= 2; L.ngx = 2; }
+      if (npy > 1) { npy /= 2; ny *= 2; L.ngy = 2; }
+      incx *= 2; incy *= 2;
+    }
+    L.nx = nx; L.ny = ny; L.nz = nz; L.npx = npx; L.npy = npy; L.incx = incx; L.incy = incy;
+  }
+  for (auto &L : T) {  // define_neighbours :580-661
+    const int ix = L.incx, iy = L.incy;
+    L.neighb[0] = (pj >= iy) ? (pj - iy) * npx0 + pi : -1;
+    L.neighb[1] = (pi < npx0 - ix) ? pj * npx0 + pi + ix : -1;
+    L.neighb[2] = (pj < npy0 - iy) ? (pj + iy) * npx0 + pi : -1;
+    L.neighb[3] = (pi >= ix) ? pj * npx0 + pi - ix : -1;
+    L.neighb[4] = (pj >= iy && pi >= ix) ? (pj - iy) * npx0 + pi - ix : -1;
+    L.neighb[5] = (pj >= iy && pi < npx0 - ix) ? (pj - iy) * npx0 + pi + ix : -1;
+    L.neighb[6] = (pj < npy0 - iy && pi < npx0 - ix) ? (pj + iy) * npx0 + pi + ix : -1;
+    L.neighb[7] = (pj < npy0 - iy && pi >= ix) ? (pj + iy) * npx0 + pi - ix : -1;
+  }
+  for (int l = 1; l < (int)T.size(); l++) {  // define_gather_informations :664-738
+    Level &L = T[l];
+    if (!L.gather) continue;
+    const int ix = L.incx / 2, iy = L.incy / 2;
+    const int family = (pi / ix) * ix * iy + npx0 * iy * (pj / iy);
+    const int nextfamily = (pi / (2 * ix)) * ix * iy * 4 + npx0 * 2 * iy * (pj / (iy * 2));
+    L.color = nextfamily + (pi % ix) + (pj % iy) * ix;
+    const int N = ix * npx0;
+    L.key = ((family % N) / (ix * iy)) % 2 + 2 * ((family / N) % 2);
+  }
+}
+
+// ---- halo exchange buffers ---------------------------------------------------------------------------
+int exchange(int n, const int *peer, double *const *sb, double *const *rb, const int *cnt) {
+  if (!S.ex) return fail("a halo exchange is needed (npx*npy > 1) but mgx_set_comm was not called");
+  S.n_exch++;
+  if (S.ex(S.ctx, n, peer, sb, rb, cnt)) return fail("exchange callback failed");
+  return 0;
+}
+
+// fill_halo_3D_relax / fill_halo_3D for the JS fields p,b,r (nh = 1): mg_mpi_exchange.f90:396-745
+int fill_halo_js(Level &L, double *a) {
+  S.n_halo++;
+  const int *nb = L.neighb;
+  Sides ph = {nb[0] < 0, nb[1] < 0, nb[2] < 0, nb[3] < 0};
+  if (ph.S || ph.E || ph.N || ph.W) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
+  int n = 0, peer[8], cnt[8], dirs[8];
+  double *sb[8], *rb[8];
+  for (int d = 0; d < 8; d++) {
+    if (nb[d] < 0) continue;
+    const int c = L.nz * ((d == 0 || d == 2) ? L.nx : ((d == 1 || d == 3) ? L.ny : 1));
+    mgxk_halo_pack(S.stream, &L.v, a, S.xbuf[d], d, 0); S.n_launch++;
+    peer[n] = nb[d]; cnt[n] = c; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d]; dirs[n] = d; n++;
+  }
+  if (n) {
+    CHK(exchange(n, peer, sb, rb, cnt));
+    for (int q = 0; q < n; q++) { mgxk_halo_pack(S.stream, &L.v, a, rb[q], dirs[q], 1); S.n_launch++; }
+    int m[4];
+    const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
+    bool any = false;
+    for (int c = 0; c < 4; c++) {
+      m[c] = 0;
+      if (nb[4 + c] < 0) { if (nb[side1[c]] >= 0) m[c] = 1; else if (nb[side2[c]] >= 0) m[c] = 2; }
+      any |= m[c] != 0;
+    }
+    if (any) { mgxk_halo_mixed_corners(S.stream, &L.v, a, m[0], m[1], m[2], m[3]); S.n_launch++; }
+  }
+  return 0;
+}
+
+// generic halo fill of a reference-layout array a(nzz,1-nh:ny+nh,1-nh:nx+nh); lbc = 0,'u','v'
+// (mg_mpi_exchange.f90:23-352 2D, :750-1242 3D incl. nh=2 extrapolation and lbc_null)
+void rect(double *a, double *buf, int op, int nzz, int nh, int ny, int j0, int j1, int i0, int i1, int mj = 0, int cj = 0, int mi = 0,
+          int ci = 0, int mj2 = 0, int cj2 = 0, int mi2 = 0, int ci2 = 0) {
+  RectOp R = {op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, mi2, ci2};
+  mgxs_rect(S.stream, a, buf, &R);
+  S.n_launch++;
+}
+
+int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c) {
+  S.n_halo++;
+  const int nx = L.nx, ny = L.ny;
+  const int *nb = L.neighb;
+  const int So = nb[0], E = nb[1], N = nb[2], W = nb[3], SW = nb[4], SE = nb[5], NE = nb[6], NW = nb[7];
+  // phase 1: physical sides, in the reference's order S,E,N,W then the corners
+  if (So < 0) {
+    if (c == 'v') rect(a, 0, 2, nzz, nh, ny, 1, 1, 1 - nh, nx + nh);
+    else { rect(a, 0, 0, nzz, nh, ny, 0, 0, 1, nx, 0, 1, 0, 0); if (nh == 2) rect(a, 0, 1, nzz, nh, ny, -1, -1, 1, nx, 0, 2, 0, 0, 0, 3, 0, 0); }
+  }
+  if (E < 0) {
+    if (c == 'u') rect(a, 0, 2, nzz, nh, ny, 1 - nh, ny + nh, nx + 1, nx + 1);
+    else { rect(a, 0, 0, nzz, nh, ny, 1, ny, nx + 1, nx + 1, 0, 0, 0, -1); if (nh == 2) rect(a, 0, 1, nzz, nh, ny, 1, ny, nx + 2, nx + 2, 0, 0, 0, -2, 0, 0, 0, -3); }
+  }
+  if (N < 0) {
+    if (c == 'v') rect(a, 0, 2, nzz, nh, ny, ny + 1, ny + 1, 1 - nh, nx + nh);
+    else { rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + 1, 1, nx, 0, -1, 0, 0); if (nh == 2) rect(a, 0, 1, nzz, nh, ny, ny + 2, ny + 2, 1, nx, 0, -2, 0, 0, 0, -3, 0, 0); }
+  }
+  if (W < 0) {
+    if (c == 'u') rect(a, 0, 2, nzz, nh, ny, 1 - nh, ny + nh, 1, 1);
+    else { rect(a, 0, 0, nzz, nh, ny, 1, ny, 0, 0, 0, 0, 0, 1); if (nh == 2) rect(a, 0, 1, nzz, nh, ny, 1, ny, -1, -1, 0, 0, 0, 2, 0, 0, 0, 3); }
+  }
+  const bool zSW = (c == 'u' && W < 0), zSE = (c == 'u' && E < 0), zNE = (c == 'u' && E < 0) || c == 'v', zNW = (c == 'u' && W < 0) || c == 'v';
+  if (SW < 0) { if (zSW) rect(a, 0, 2, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0); else if (So < 0 && W < 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 1, 1, 1, 1); }
+  if (SE < 0) { if (zSE) rect(a, 0, 2, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh); else if (So < 0 && E < 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 1, 1, 1, 2 * nx + 1); }
+  if (NE < 0) { if (zNE) rect(a, 0, 2, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh); else if (N < 0 && E < 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh, 1, 2 * ny + 1, 1, 2 * nx + 1); }
+  if (NW < 0) { if (zNW) rect(a, 0, 2, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0); else if (N < 0 && W < 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0, 1, 2 * ny + 1, 1, 1); }
+  // phase 2: exchange with the existing neighbours
+  int n = 0, peer[8], cnt[8];
+  double *sb[8], *rb[8];
+  int rr[8][4];
+  for (int d = 0; d < 8; d++) {
+    if (nb[d] < 0) continue;
+    int sj0, sj1, si0, si1, rj0, rj1, ri0, ri1;
+    const bool south = (d == 0 || d == 4 || d == 5), north = (d == 2 || d == 6 || d == 7);
+    const bool east = (d == 1 || d == 5 || d == 6), west = (d == 3 || d == 4 || d == 7);
+    if (south) { sj0 = 1; sj1 = nh; rj0 = 1 - nh; rj1 = 0; } else if (north) { sj0 = ny - nh + 1; sj1 = ny; rj0 = ny + 1; rj1 = ny + nh; } else { sj0 = rj0 = 1; sj1 = rj1 = ny; }
+    if (west) { si0 = 1; si1 = nh; ri0 = 1 - nh; ri1 = 0; } else if (east) { si0 = nx - nh + 1; si1 = nx; ri0 = nx + 1; ri1 = nx + nh; } else { si0 = ri0 = 1; si1 = ri1 = nx; }
+    const int count = nzz * (sj1 - sj0 + 1) * (si1 - si0 + 1);
+    if ((size_t)count > S.xbuf_n) return fail("halo buffer too small");
+    rect(a, S.xbuf[d], 3, nzz, nh, ny, sj0, sj1, si0, si1);
+    peer[n] = nb[d]; cnt[n] = count; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d];
+    rr[n][0] = rj0; rr[n][1] = rj1; rr[n][2] = ri0; rr[n][3] = ri1; n++;
+  }
+  if (n) {
+    CHK(exchange(n, peer, sb, rb, cnt));
+    for (int q = 0; q < n; q++) rect(a, rb[q], 4, nzz, nh, ny, rr[q][0], rr[q][1], rr[q][2], rr[q][3]);
+  }
+  // phase 3: mixed corners (:1216-1240)
+  if (SW < 0 && !zSW) { if (So >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 0, 0, 1, 1); else if (W >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 1, 1, 0, 0); }
+  if (SE < 0 && !zSE) { if (So >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 0, 0, 1, 2 * nx + 1); else if (E >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 1, 1, 0, 0); }
+  if (NE < 0 && !zNE) { if (N >= 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh, 0, 0, 1, 2 * nx + 1); else if (E >= 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh, 1, 2 * ny + 1, 0, 0); }
+  if (NW < 0 && !zNW) { if (N >= 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0, 0, 0, 1, 1); else if (W >= 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0, 1, 2 * ny + 1, 0, 0); }
+  return 0;
+}
+
+// global_sum (mg_mpi_exchange.f90:1555-1571) of the value in d_scalar[0]; returns it on the host
+int global_sum(const Level &L, double *out) {
+  if (S.nranks > 1) {
+    if (!S.ar) return fail("an all-reduce is needed (npx*npy > 1) but mgx_set_comm was not called");
+    S.n_allred++;
+    if (S.ar(S.ctx, S.d_scalar, 1)) return fail("allreduce callback failed");
+  }
+  HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipStreamSynchronize(S.stream));
+  *out = S.h_scalar[0] * (L.npx * L.npy) / (S.lev[0].npx * S.lev[0].npy);
+  return 0;
+}
+
+// ---- operators ------------------------------------------------------------------------------------
+// mg_relax.f90:16-47 relax ; :151-190 RB ; :193-234 FC
+int relax(int lev, int nsweeps) {
+  Level &L = S.lev[lev - 1];
+  if (S.method == M_GS)
+    return fail("relax_method='GS' is a sequential lexicographic sweep (mg_relax.f90:131-144); this build runs the parallel orderings 'RB' and 'FC' only");
+  for (int it = 1; it <= nsweeps; it++) {
+    if (S.method == M_RB) {
+      for (int rb = 1; rb <= 2; rb++) {
+        if (S.real) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
+        mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real); S.n_launch++;
+        CHK(fill_halo_js(L, L.v.p));
+      }
+    } else {
+      for (int fc1 = 1; fc1 <= 2; fc1++)
+        for (int fc2 = 1; fc2 <= 2; fc2++) {
+          mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0); S.n_launch++;
+          CHK(fill_halo_js(L, L.v.p));
+        }
+    }
+  }
+  return 0;
+}
+
+// mg_relax.f90:337-383 compute_residual.  res == nullptr: the caller discards the norm (mg_solvers.f90:140),
+// so neither the reduction nor the all-reduce is issued.
+int residual(int lev, double *res) {
+  Level &L = S.lev[lev - 1];
+  mgxk_residual(S.stream, &L.v, S.d_partial, S.d_scalar, S.real, res != nullptr); S.n_launch += res ? 2 : 1;
+  CHK(fill_halo_js(L, L.v.r));
+  if (res) { double s; CHK(global_sum(L, &s)); *res = sqrt(s); }
+  return 0;
+}
+
+// mg_intergrids.f90:16-72
+int fine2coarse(int lev) {
+  Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  if (!C.gather) {
+    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b); S.n_launch++;
+  } else {
+    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b); S.n_launch++;
+    mgxk_block_to_ref(S.stream, &C.vs, C.vs.b, C.blk); S.n_launch++;
+    const int Ng = C.nz * (C.vs.ny + 2) * (C.vs.nx + 2);
+    if (!S.ag) return fail("a gather is needed but mgx_set_comm was not called");
+    if (S.ag(S.ctx, C.group, C.ngroup, C.blk, C.gbuf, Ng)) return fail("allgather callback failed");
+    for (int q = 0; q < C.ngroup; q++) {
+      mgxk_gather_place(S.stream, &C.v, C.v.b, C.gbuf + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx); S.n_launch++;
+    }
+  }
+  CHK(fill_halo_js(C, C.v.b));
+  HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
+  return 0;
+}
+
+// mg_intergrids.f90:167-228
+int coarse2fine(int lev) {
+  Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  if (!C.gather) {
+    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear); S.n_launch++;
+  } else {
+    mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear); S.n_launch++;
+  }
+  CHK(fill_halo_js(F, F.v.r));
+  // p = p + r over the whole array: the interior was updated by the kernel; the halo of p + halo of r
+  // equals the halo fill of the updated p (both are images of the same interior cells)
+  CHK(fill_halo_js(F, F.v.p));
+  return 0;
+}
+
+// mg_solvers.f90:129-151
+int vcycle(int lev1) {
+  for (int lev = lev1; lev <= S.nlevs - 1; lev++) {
+    CHK(relax(lev, S.par.ns_pre));
+    CHK(residual(lev, nullptr));
+    CHK(fine2coarse(lev));
+  }
+  CHK(relax(S.nlevs, S.par.ns_coarsest));
+  for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
+    CHK(coarse2fine(lev));
+    CHK(relax(lev, S.par.ns_post));
+  }
+  return 0;
+}
+
+// mg_solvers.f90:104-126
+int fcycle() {
+  for (int lev = 1; lev <= S.nlevs - 1; lev++) {
+    CHK(fine2coarse(lev));
+    Level &C = S.lev[lev];
+    HIPCHK(hipMemcpyAsync(C.v.r, C.v.b, C.n3js * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+  }
+  CHK(relax(S.nlevs, S.par.ns_coarsest));
+  for (int lev = S.nlevs - 1; lev >= 1; lev--) {
+    CHK(coarse2fine(lev));
+    CHK(vcycle(lev));
+  }
+  return 0;
+}
+
+// mg_solvers.f90:17-101
+int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist) {
+  Level &L = S.lev[0];
+  if (S.verbose && S.rank == 0) printf(" - solve p:\n");
+  HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));
+  mgxk_sumsq(S.stream, &L.v, L.v.b, S.d_partial, S.d_scalar); S.n_launch += 2;
+  double bnorm; CHK(global_sum(L, &bnorm)); bnorm = sqrt(bnorm);
+  int nite = 0;
+  double rnorm; CHK(residual(1, &rnorm));
+  double res0 = rnorm / bnorm;
+  if (hist) hist[0] = res0;
+  FILE *f100 = (S.verbose && S.rank == 0) ? fopen("fort.100", "a") : nullptr;
+  if (f100) fprintf(f100, " %24.16E %d\n", res0, nite);
+  while (nite < maxite && res0 > tol) {
+    CHK(fcycle());
+    CHK(residual(1, &rnorm));
+    rnorm = rnorm / bnorm;
+    const double conv = res0 / rnorm;
+    res0 = rnorm;
+    nite++;
+    if (hist) hist[nite] = rnorm;
+    if (S.verbose && S.rank == 0) printf("ite = %2d: res = %10.3E / conv = %10.3f\n", nite, rnorm, conv);
+    if (f100) fprintf(f100, " %24.16E %24.16E\n", rnorm, conv);
+  }
+  if (f100) fclose(f100);
+  if (nite_out) *nite_out = nite;
+  if (res_out) *res_out = res0;
+  return 0;
+}
+
+// ---- set-up: mg_define_matrix.f90:28-208 ----------------------------------------------------------
+int gather2d(Level &L, double *src_tmp, double *dst) {
+  const int nxc = L.nx / L.ngx, nyc = L.ny / L.ngy, Ng = nxc * nyc;
+  rect(src_tmp, L.blk, 3, 1, 1, nyc, 1, nyc, 1, nxc);
+  if (!S.ag) return fail("a gather is needed but mgx_set_comm was not called");
+  if (S.ag(S.ctx, L.group, L.ngroup, L.blk, L.gbuf, Ng)) return fail("allgather callback failed");
+  for (int q = 0; q < L.ngroup; q++) {
+    const int l = q % L.ngx, m = q / L.ngx;
+    rect(dst, L.gbuf + (size_t)q * Ng, 4, 1, 1, L.ny, 1 + m * nyc, (m + 1) * nyc, 1 + l * nxc, (l + 1) * nxc);
+  }
+  return 0;
+}
+
+int define_matrices() {
+  for (int l = 0; l < S.nlevs; l++) {
+    Level &L = S.lev[l];
+    if (l > 0) {
+      Level &F = S.lev[l - 1];
+      const int nxc = L.gather ? L.nx / L.ngx : L.nx, nyc = L.gather ? L.ny / L.ngy : L.ny;
+      double *src[4] = {F.g.dx, F.g.dy, F.g.zeta, F.g.h};
+      double *own[4] = {L.g.dx, L.g.dy, L.g.zeta, L.g.h};
+      const double fac[4] = {0.5, 0.5, 0.25, 0.25};
+      for (int q = 0; q < 4; q++) {
+        mgxs_coarsen2d(S.stream, src[q], L.gather ? L.tmp2[q] : own[q], F.ny, nyc, nxc, fac[q]); S.n_launch++;
+        if (L.gather) CHK(gather2d(L, L.tmp2[q], own[q]));
+      }
+    }
+    CHK(rl_fill_halo(L, L.g.dx, 1, 1, 0));
+    CHK(rl_fill_halo(L, L.g.dy, 1, 1, 0));
+    CHK(rl_fill_halo(L, L.g.zeta, 1, 1, 0));
+    CHK(rl_fill_halo(L, L.g.h, 1, 1, 0));
+    mgxs_zr_zw(S.stream, &L.g, S.hlim, S.theta_b, S.theta_s); S.n_launch++;
+    CHK(rl_fill_halo(L, L.g.zr, L.nz, 2, 0));
+    CHK(rl_fill_halo(L, L.g.zw, L.nz + 1, 2, 0));
+    HIPCHK(hipMemsetAsync(L.g.cA, 0, (size_t)8 * L.nz * (L.ny + 2) * (L.nx + 2) * sizeof(double), S.stream));
+    mgxs_define_matrix(S.stream, &L.g, l == 0); S.n_launch += 3;
+    for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
+    mgxs_pivots(S.stream, &L.v); S.n_launch++;
+  }
+  HIPCHK(hipStreamSynchronize(S.stream));
+  S.have_matrix = true;
+  return 0;
+}
+
+// mg_compute_rhs.f90:14-379 on the device copies of u,v,w
+int compute_rhs_dev() {
+  Level &L = S.lev[0];
+  ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+  HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));
+  mgxs_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
+  CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'u'));
+  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 0); S.n_launch++;
+  mgxs_rhs_vf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
+  CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'v'));
+  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 1); S.n_launch++;
+  mgxs_rhs_wf(S.stream, &L.g, &M, S.d_fz); S.n_launch++;
+  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fz, 2); S.n_launch++;
+  return 0;
+}
+
+int upload_uvw(const double *u, const double *v, const double *w) {
+  Level &L = S.lev[0];
+  const size_t nu = (size_t)(L.nx + 1) * (L.ny + 2) * L.nz, nv = (size_t)(L.nx + 2) * (L.ny + 1) * L.nz, nw = (size_t)(L.nx + 2) * (L.ny + 2) * (L.nz + 1);
+  HIPCHK(hipMemcpyAsync(S.d_u, u, nu * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipMemcpyAsync(S.d_v, v, nv * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipMemcpyAsync(S.d_w, w, nw * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  return 0;
+}
+
+bool streq(const char *a, const char *b) { return strcmp(a, b) == 0; }
+
+int apply_params(const mgx_params &p) {
+  if (streq(p.relax_method, "GS") || streq(p.relax_method, "Gauss-Seidel")) S.method = M_GS;
+  else if (streq(p.relax_method, "RB") || streq(p.relax_method, "Red-Black")) S.method = M_RB;
+  else if (streq(p.relax_method, "FC") || streq(p.relax_method, "Four-Color")) S.method = M_FC;
+  else return fail("unknown relax_method '%s'", p.relax_method);
+  S.real = streq(p.cmatrix, "real") ? 1 : 0;
+  if (streq(p.interp_type, "linear")) S.linear = 1; else if (streq(p.interp_type, "nearest")) S.linear = 0; else return fail("unknown interp_type '%s'", p.interp_type);
+  if (S.linear && streq(p.restrict_type, "linear")) return fail("linear interp + linear restrict is not permitted");
+  if (p.aggressive) return fail("aggressive=.true.: coarse2fine_aggressive is not available in the reference either (mg_intergrids.f90:243)");
+  if (p.bmask) return fail("bmask=.true. is not supported by this build (SURVEY 8 row f3)");
+  S.par = p;
+  return 0;
+}
+
+void trim(std::string &s) {
+  size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n,");
+  s = (a == std::string::npos) ? "" : s.substr(a, b - a + 1);
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+const char *mgx_last_error(void) { return S.err.c_str(); }
+const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+int mgx_set_verbose(int v) { S.verbose = v; return 0; }
+int mgx_set_stream(void *st) { S.stream = (hipStream_t)st; return 0; }
+int mgx_set_comm(mgx_exchange_fn ex, mgx_allreduce_fn ar, mgx_allgather_fn ag, void *ctx) { S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx; return 0; }
+
+int mgx_params_default(mgx_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->solver_prec = 1e-6; p->solver_maxiter = 50; p->nsmall = 8; p->ns_coarsest = 40; p->ns_pre = 3; p->ns_post = 2;
+  strcpy(p->cmatrix, "real"); strcpy(p->relax_method, "RB"); strcpy(p->interp_type, "linear"); strcpy(p->restrict_type, "avg");
+  return 0;
+}
+
+int mgx_read_namelist(const char *path, mgx_params *p) {
+  FILE *f = fopen(path ? path : "nh_namelist", "r");
+  if (!f) return 0;  // defaults stay (mg_namelist.f90:75-86)
+  std::string txt; char line[1024];
+  while (fgets(line, sizeof(line), f)) { std::string s(line); size_t c = s.find('!'); if (c != std::string::npos) s = s.substr(0, c); txt += s + "\n"; }
+  fclose(f);
+  size_t a = txt.find("&nhparam");
+  if (a == std::string::npos) return fail("namelist group &nhparam not found in %s", path ? path : "nh_namelist");
+  size_t e = txt.find('/', a);
+  std::string body = txt.substr(a + 8, e == std::string::npos ? std::string::npos : e - a - 8);
+  size_t pos = 0;
+  while (pos < body.size()) {  // scalar assignments "key = value", separated by commas and/or newlines
+    size_t end = body.find_first_of(",\n", pos);
+    if (end == std::string::npos) end = body.size();
+    std::string stmt = body.substr(pos, end - pos);
+    pos = end + 1;
+    size_t eq = stmt.find('=');
+    if (eq == std::string::npos) { trim(stmt); if (!stmt.empty()) return fail("cannot parse namelist statement '%s'", stmt.c_str()); continue; }
+    std::string key = stmt.substr(0, eq), val = stmt.substr(eq + 1);
+    trim(key); trim(val);
+    for (auto &ch : key) ch = (char)tolower(ch);
+    std::string sv = val;
+    if (sv.size() >= 2 && (sv[0] == '\'' || sv[0] == '"')) sv = sv.substr(1, sv.size() - 2);
+    auto num = [&](void) { std::string t = val; for (auto &ch : t) if (ch == 'd' || ch == 'D') ch = 'e'; return atof(t.c_str()); };
+    auto lg = [&](void) { std::string t = val; for (auto &ch : t) ch = (char)tolower(ch); return (t.find(".t") == 0 || t == "t") ? 1 : 0; };
+    if (key == "solver_prec") p->solver_prec = num();
+    else if (key == "solver_maxiter") p->solver_maxiter = (int)num();
+    else if (key == "nsmall") p->nsmall = (int)num();
+    else if (key == "ns_coarsest") p->ns_coarsest = (int)num();
+    else if (key == "ns_pre") p->ns_pre = (int)num();
+    else if (key == "ns_post") p->ns_post = (int)num();
+    else if (key == "cmatrix") snprintf(p->cmatrix, 16, "%s", sv.c_str());
+    else if (key == "relax_method") snprintf(p->relax_method, 16, "%s", sv.c_str());
+    else if (key == "interp_type") snprintf(p->interp_type, 16, "%s", sv.c_str());
+    else if (key == "restrict_type") snprintf(p->restrict_type, 16, "%s", sv.c_str());
+    else if (key == "aggressive") p->aggressive = lg();
+    else if (key == "netcdf_output") p->netcdf_output = lg();
+    else if (key == "bmask") p->bmask = lg();
+    else return fail("'%s' is not a member of namelist /nhparam/", key.c_str());  // a Fortran read would abort too
+  }
+  if (streq(p->interp_type, "linear") && streq(p->restrict_type, "linear")) return fail("linear interp + linear restrict is not permitted");
+  return 0;
+}
+
+void mgx_clean(void) {
+  if (S.stream || S.inited) hipStreamSynchronize(S.stream);
+  for (void *q : S.allocs) hipFree(q);
+  if (S.h_scalar) hipHostFree(S.h_scalar);
+  hipStream_t st = S.stream; int vb = S.verbose;
+  mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx;
+  S = State();
+  S.stream = st; S.verbose = vb; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+}
+
+int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
+  if (S.inited) mgx_clean();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible: libmgx has no CPU path");
+  mgx_params p;
+  if (par) p = *par; else { mgx_params_default(&p); CHK(mgx_read_namelist(nullptr, &p)); }
+  CHK(apply_params(p));
+  if (nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1)) return fail("nx,ny,nz must be even and >= 2 (got %d %d %d)", nx, ny, nz);
+  if (rank < 0 || rank >= npx * npy) return fail("rank %d outside the %d x %d process grid", rank, npx, npy);
+  S.npx = npx; S.npy = npy; S.nranks = npx * npy; S.rank = rank; S.pi = rank % npx; S.pj = rank / npx;
+  S.nlevs = find_grid_levels(npx, npy, nx, ny, nz);
+  if (S.nlevs < 1) return fail("grid %dx%dx%d too small for a multigrid hierarchy", nx * npx, ny * npy, nz);
+  S.lev.assign(S.nlevs, Level());
+  S.lev[0].nx = nx; S.lev[0].ny = ny; S.lev[0].nz = nz;
+  rank_level_table(rank, S.lev);
+  for (int l = 0; l < S.nlevs; l++) {
+    const Level &L = S.lev[l];
+    if ((L.nx & 1) || (L.ny & 1) || L.nz < 2) return fail("level %d has local size %dx%dx%d: odd sizes are not supported (assumptions:1-2)", l + 1, L.nx, L.ny, L.nz);
+  }
+  // gather groups: ranks with my colour, ordered by (key, rank)  (MPI_COMM_SPLIT, mg_grids.f90:717)
+  for (int l = 1; l < S.nlevs; l++) {
+    Level &L = S.lev[l];
+    if (!L.gather) continue;
+    std::vector<std::pair<int, int>> mem;
+    for (int r = 0; r < S.nranks; r++) {
+      std::vector<Level> T(S.nlevs);
+      T[0].nx = nx; T[0].ny = ny; T[0].nz = nz;
+      rank_level_table(r, T);
+      if (T[l].color == L.color) mem.push_back({T[l].key, r});
+    }
+    std::sort(mem.begin(), mem.end());
+    L.ngroup = (int)mem.size();
+    if (L.ngroup != L.ngx * L.ngy) return fail("gather group of level %d has %d members, expected %d", l + 1, L.ngroup, L.ngx * L.ngy);
+    for (int q = 0; q < L.ngroup; q++) L.group[q] = mem[q].second;
+  }
+  // allocations
+  size_t max_part = 1;
+  for (int l = 0; l < S.nlevs; l++) {
+    Level &L = S.lev[l];
+    make_view(L.v, L.nx, L.ny, L.nz);
+    L.n3js = (size_t)(L.nx + 2) * L.v.plane;
+    CHK(dmalloc(&L.v.p, L.n3js)); CHK(dmalloc(&L.v.b, L.n3js)); CHK(dmalloc(&L.v.r, L.n3js));
+    for (int s = 0; s < 8; s++) CHK(dmalloc(&L.v.cA[s], L.n3js));
+    CHK(dmalloc(&L.v.bet, L.n3js)); CHK(dmalloc(&L.v.gam, L.n3js));
+    CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS));
+    const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
+    L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
+    CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));
+    CHK(dmalloc(&L.g.zr, (size_t)(L.ny + 4) * (L.nx + 4) * L.nz));
+    CHK(dmalloc(&L.g.zw, (size_t)(L.ny + 4) * (L.nx + 4) * (L.nz + 1)));
+    CHK(dmalloc(&L.g.cw, n2 * (L.nz + 1)));
+    L.g.dzw = L.g.zxdy = L.g.zydx = nullptr;
+    if (l == 0) { CHK(dmalloc(&L.g.dzw, n2 * (L.nz + 1))); CHK(dmalloc(&L.g.zxdy, n2 * L.nz)); CHK(dmalloc(&L.g.zydx, n2 * L.nz)); }
+    if (L.gather) {
+      const int nxc = L.nx / L.ngx, nyc = L.ny / L.ngy;
+      L.vs = L.v;
+      make_view(L.vs, nxc, nyc, L.nz);
+      const size_t ns = (size_t)(nxc + 2) * L.vs.plane;
+      CHK(dmalloc(&L.vs.b, ns)); CHK(dmalloc(&L.vs.p, ns));
+      const size_t Ng = (size_t)L.nz * (nyc + 2) * (nxc + 2);
+      CHK(dmalloc(&L.blk, Ng)); CHK(dmalloc(&L.gbuf, Ng * L.ngroup));
+      for (int q = 0; q < 4; q++) CHK(dmalloc(&L.tmp2[q], (size_t)(nyc + 2) * (nxc + 2)));
+    }
+    const size_t np = (size_t)mgxk_residual_nblocks(&L.v);
+    if (np > max_part) max_part = np;
+  }
+  S.npartial = (int)max_part;
+  CHK(dmalloc(&S.d_partial, max_part));
+  CHK(dmalloc(&S.d_scalar, 8));
+  HIPCHK(hipHostMalloc((void **)&S.h_scalar, 8 * sizeof(double)));
+  Level &L1 = S.lev[0];
+  S.ref_scratch_n = (size_t)8 * L1.nz * (L1.ny + 2) * (L1.nx + 2);
+  CHK(dmalloc(&S.ref_scratch, S.ref_scratch_n));
+  for (auto &L : S.lev) L.g.cA = S.ref_scratch;
+  S.xbuf_n = (size_t)(L1.nz + 1) * 2 * ((L1.nx > L1.ny ? L1.nx : L1.ny) + 4);
+  for (int q = 0; q < 16; q++) CHK(dmalloc(&S.xbuf[q], S.xbuf_n));
+  CHK(dmalloc(&S.d_u, (size_t)(L1.nx + 1) * (L1.ny + 2) * L1.nz));
+  CHK(dmalloc(&S.d_v, (size_t)(L1.nx + 2) * (L1.ny + 1) * L1.nz));
+  CHK(dmalloc(&S.d_w, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
+  CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  HIPCHK(hipStreamSynchronize(S.stream));
+  S.inited = true;
+  if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
+    printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
+           "   - ns_pre        : %d\n   - ns_post       : %d\n   - cmatrix       : %s\n   - relax_method  : %s\n   - interp_type   : %s\n"
+           "   - restrict_type : %s\n   - aggressive    : %c\n   - netcdf_output : %c\n   - bmask         : %c\n\n",
+           p.solver_prec, p.solver_maxiter, p.nsmall, p.ns_coarsest, p.ns_pre, p.ns_post, p.cmatrix, p.relax_method, p.interp_type,
+           p.restrict_type, p.aggressive ? 'T' : 'F', p.netcdf_output ? 'T' : 'F', p.bmask ? 'T' : 'F');
+    printf(" - print grid information:\n");
+    for (int l = 0; l < S.nlevs; l++) {
+      const Level &L = S.lev[l];
+      printf("  lev=%2d: %3d x%3d x%3d on %3d x%3d procs%s\n", l + 1, L.nx, L.ny, L.nz, L.npx, L.npy, L.gather ? " / gather" : "");
+    }
+  }
+  return 0;
+}
+
+int mgx_matrices(const double *dx, const double *dy, const double *zeta, const double *h, const double *rmask, double hc,
+                 double theta_b, double theta_s) {
+  NEED_INIT();
+  (void)rmask;  // only read when bmask=.true., which mgx_init rejects
+  if (S.verbose && S.rank == 0) printf("  nhydro_matrices:\n");
+  S.hlim = hc; S.theta_b = theta_b; S.theta_s = theta_s;
+  Level &L = S.lev[0];
+  const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2) * sizeof(double);
+  HIPCHK(hipMemcpyAsync(L.g.dx, dx, n2, hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipMemcpyAsync(L.g.dy, dy, n2, hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipMemcpyAsync(L.g.zeta, zeta, n2, hipMemcpyHostToDevice, S.stream));
+  HIPCHK(hipMemcpyAsync(L.g.h, h, n2, hipMemcpyHostToDevice, S.stream));
+  return define_matrices();
+}
+
+int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask) {
+  NEED_INIT();
+  (void)rmask;
+  if (!S.have_matrix) return fail("mgx_matrices must be called before compute_rhs");
+  CHK(upload_uvw(u, v, w));
+  CHK(compute_rhs_dev());
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int mgx_solve(double *u, double *v, double *w, const double *rmask) {
+  NEED_INIT();
+  (void)rmask;
+  if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve");
+  if (S.verbose && S.rank == 0) printf("  nhydro_solve:\n");
+  CHK(upload_uvw(u, v, w));
+  CHK(compute_rhs_dev());
+  CHK(solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr));
+  Level &L = S.lev[0];
+  ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+  mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
+  const size_t nu = (size_t)(L.nx + 1) * (L.ny + 2) * L.nz, nv = (size_t)(L.nx + 2) * (L.ny + 1) * L.nz, nw = (size_t)(L.nx + 2) * (L.ny + 2) * (L.nz + 1);
+  HIPCHK(hipMemcpyAsync(u, S.d_u, nu * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(v, S.d_v, nv * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(w, S.d_w, nw * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int mgx_check_nondivergence(double *u, double *v, double *w, const double *rmask) {
+  if (S.verbose && S.rank == 0) printf(" - check non-divergence:\n");
+  return mgx_compute_rhs(u, v, w, rmask);
+}
+
+int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist) {
+  NEED_INIT();
+  if (!S.have_matrix) return fail("no matrix: call mgx_matrices (or mgx_set_field(lev, MGX_CA, ...)) first");
+  return solve_p(tol, maxite, nite, res, hist);
+}
+int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_residual(int lev, double *res) { NEED_LEV(lev); double r; CHK(residual(lev, &r)); if (res) *res = r; return 0; }
+int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_fill_halo(int lev, int field) {
+  NEED_LEV(lev);
+  Level &L = S.lev[lev - 1];
+  double *a = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : (field == MGX_R ? L.v.r : nullptr));
+  if (!a) return fail("fill_halo: field %d is not one of p,b,r", field);
+  CHK(fill_halo_js(L, a));
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }
+int mgx_level_dims(int lev, int *nx, int *ny, int *nz) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *nx = L.nx; *ny = L.ny; *nz = L.nz; return 0; }
+int mgx_level_info(int lev, int *out) {
+  NEED_LEV(lev);
+  const Level &L = S.lev[lev - 1];
+  const int v[10] = {L.npx, L.npy, L.incx, L.incy, L.gather, L.ngx, L.ngy, L.key, L.color, 0};
+  memcpy(out, v, sizeof(v)); memcpy(out + 10, L.neighb, 8 * sizeof(int));
+  return 0;
+}
+
+static int field_ptr(Level &L, int field, double **a, size_t *n) {
+  const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
+  switch (field) {
+    case MGX_DX: *a = L.g.dx; *n = n2; return 0;
+    case MGX_DY: *a = L.g.dy; *n = n2; return 0;
+    case MGX_ZETA: *a = L.g.zeta; *n = n2; return 0;
+    case MGX_H: *a = L.g.h; *n = n2; return 0;
+    case MGX_ZR: *a = L.g.zr; *n = (size_t)(L.ny + 4) * (L.nx + 4) * L.nz; return 0;
+    case MGX_ZW: *a = L.g.zw; *n = (size_t)(L.ny + 4) * (L.nx + 4) * (L.nz + 1); return 0;
+    case MGX_CW: *a = L.g.cw; *n = n2 * (L.nz + 1); return 0;
+  }
+  return 1;
+}
+
+int mgx_get_field(int lev, int field, double *host) {
+  NEED_LEV(lev);
+  Level &L = S.lev[lev - 1];
+  const size_t n3 = (size_t)L.nz * (L.ny + 2) * (L.nx + 2);
+  double *a; size_t n;
+  if (field == MGX_P || field == MGX_B || field == MGX_R) {
+    double *js = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : L.v.r);
+    mgxk_convert(S.stream, &L.v, js, S.ref_scratch, 1, 0, 1);
+    HIPCHK(hipMemcpyAsync(host, S.ref_scratch, n3 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  } else if (field == MGX_CA) {
+    for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 1);
+    HIPCHK(hipMemcpyAsync(host, S.ref_scratch, 8 * n3 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  } else if (!field_ptr(L, field, &a, &n)) {
+    HIPCHK(hipMemcpyAsync(host, a, n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  } else return fail("get_field: unknown field id %d", field);
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+int mgx_set_field(int lev, int field, const double *host) {
+  NEED_LEV(lev);
+  Level &L = S.lev[lev - 1];
+  const size_t n3 = (size_t)L.nz * (L.ny + 2) * (L.nx + 2);
+  double *a; size_t n;
+  if (field == MGX_P || field == MGX_B || field == MGX_R) {
+    double *js = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : L.v.r);
+    HIPCHK(hipMemcpyAsync(S.ref_scratch, host, n3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    mgxk_convert(S.stream, &L.v, js, S.ref_scratch, 1, 0, 0);
+  } else if (field == MGX_CA) {
+    HIPCHK(hipMemcpyAsync(S.ref_scratch, host, 8 * n3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 0);
+    mgxs_pivots(S.stream, &L.v);
+    S.have_matrix = true;
+  } else if (!field_ptr(L, field, &a, &n)) {
+    HIPCHK(hipMemcpyAsync(a, host, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  } else return fail("set_field: unknown field id %d", field);
+  HIPCHK(hipStreamSynchronize(S.stream));
+  return 0;
+}
+
+static int time_op(int lev, int reps, float *ms, int which) {
+  NEED_LEV(lev);
+  if (reps < 1) return fail("reps must be >= 1");
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, S.stream));
+  for (int q = 0; q < reps; q++) { if (which == 0) CHK(relax(lev, 1)); else CHK(residual(lev, nullptr)); }
+  HIPCHK(hipEventRecord(e1, S.stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms = t / reps;
+  return 0;
+}
+int mgx_time_relax(int lev, int reps, float *ms) { return time_op(lev, reps, ms, 0); }
+int mgx_time_residual(int lev, int reps, float *ms) { return time_op(lev, reps, ms, 1); }
+int mgx_counters(long long *out) { out[0] = S.n_launch; out[1] = S.n_halo; out[2] = S.n_exch; out[3] = S.n_allred; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Internal declarations shared by the HIP translation units of libmgx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// Device view of one grid level.  Solver fields use the "JS" layout:
+//   element (k,j,i), k=1..nz, j=0..ny+1, i=0..nx+1  ->  i*plane + (k-1)*RS + pos(j)
+//   pos(j) = (j odd) ? HO + j/2 : EO + j/2
+// i.e. i-planes of nz rows; inside a row the even-j and the odd-j columns are stored as two contiguous
+// halves.  A colour of the z-line smoother (fixed j parity in a plane) is then a unit-stride run of
+// columns, and EO/HO are chosen so that the first interior column of either half is 128-byte aligned.
+struct LevView {
+  int nx, ny, nz;
+  int RS, EO, HO;
+  long long plane;  // nz * RS
+  double *p, *b, *r;
+  double *cA[8];    // slots 1..8 of the reference's cA(8,k,j,i), one JS array each
+  double *bet;      // reciprocal pivots of the column tridiagonal (tridiag's `bet`, mg_relax.f90:322-327)
+  double *gam;      // tridiag's `gam(k)` (mg_relax.f90:325)
+  double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
+};
+
+__host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }
+
+// Reference-layout (Fortran order) views used by set-up, compute_rhs and correct_uvw.
+struct GeoView {
+  int nx, ny, nz;
+  double *dx, *dy, *zeta, *h;  // (0:ny+1, 0:nx+1)
+  double *zr;                  // (nz,   -1:ny+2, -1:nx+2)
+  double *zw;                  // (nz+1, -1:ny+2, -1:nx+2)
+  double *cw;                  // (nz+1, 0:ny+1, 0:nx+1)
+  double *cA;                  // (8, nz, 0:ny+1, 0:nx+1)   scratch shared by all levels
+  double *dzw, *zxdy, *zydx;   // level 1 only
+};
+
+// physical-boundary flags of a sub-domain (1 = no neighbour on that side)
+struct Sides { int S, E, N, W; };

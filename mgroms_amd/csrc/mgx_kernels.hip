@@ -1,0 +1,472 @@
+// HIP kernels of the multigrid cycle for gfx950 (MI355X).  Hand-written, fp64, bandwidth-bound stencils.
+//
+// All arithmetic keeps the reference's operation order and is compiled with -ffp-contract=off, so a
+// colour pass of the four-colour smoother, the residual and the transfers are bit-identical to the
+// reference's CPU loops (only reductions differ in summation order).
+//
+// Thread mapping everywhere: one lane = one (j,i) column, lanes run along the unit-stride half-row of
+// the JS layout (mgx_internal.h), so every global access of a wave is one contiguous 512-byte run.
+#include "mgx_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// z-line smoother, one colour pass.  mg_relax.f90:237-305 (relax_3D_8_heart) + :308-334 (tridiag).
+// Columns of one colour never read each other (four-colour), or only through the k=1 horizontal
+// diagonals (red-black): those are then read from the snapshot L.p1 taken before the pass (SNAP).
+// The tridiagonal pivots (bet, gam) depend on the matrix only and are precomputed at set-up.
+// ------------------------------------------------------------------------------------------------
+template <bool REAL, bool SNAP>
+__global__ __launch_bounds__(256) void k_relax_colour(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int ipl = blockIdx.y * blockDim.y + threadIdx.y;
+  if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
+  const int i = i0 + istep * ipl;
+  // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
+  const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  int c, jm, jp;  // positions of columns j, j-1, j+1 inside a row
+  if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+  else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+  const long long RS = L.RS;
+  const int nz = L.nz;
+  double *__restrict__ p = L.p;
+  const double *__restrict__ b = L.b;
+  const double *__restrict__ a2 = L.cA[1], *__restrict__ a3 = L.cA[2], *__restrict__ a4 = L.cA[3],
+               *__restrict__ a5 = L.cA[4], *__restrict__ a6 = L.cA[5], *__restrict__ a7 = L.cA[6],
+               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ gam = L.gam;
+  const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+
+  // neighbour rows: p of (j-1,i) and (j,i-1); products coef*p of (j+1,i) [slots 3,4,5] and (j,i+1) [6,7,8]
+  double pjm_m, pjm_0, pjm_p, pim_m, pim_0, pim_p;
+  double m3_m, m3_0, m4_0, m5_p, n6_m, n6_0, n7_0, n8_p;
+  double m3_p, m4_p, n6_p, n7_p;
+#define LOAD_ROW(q, PJM, PIM, M3, M4, M5, N6, N7, N8)                         \
+  {                                                                            \
+    const long long ro = (long long)((q)-1) * RS;                              \
+    PJM = p[o + ro + jm];                                                      \
+    PIM = p[om + ro + c];                                                      \
+    const double pj_ = p[o + ro + jp], pi_ = p[op + ro + c];                   \
+    M3 = a3[o + ro + jp] * pj_; M4 = a4[o + ro + jp] * pj_; M5 = a5[o + ro + jp] * pj_; \
+    N6 = a6[op + ro + c] * pi_; N7 = a7[op + ro + c] * pi_; N8 = a8[op + ro + c] * pi_; \
+  }
+  double dum5, dum8;
+  LOAD_ROW(1, pjm_0, pim_0, m3_0, m4_0, dum5, n6_0, n7_0, dum8);
+  LOAD_ROW(2, pjm_p, pim_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p);
+  (void)dum5; (void)dum8;
+
+  // ---- k = 1 (mg_relax.f90:262-279)
+  double rhs = b[o + c] - a3[o + c] * pjm_p - a4[o + c] * pjm_0 - m4_0 - m5_p - a6[o + c] * pim_p - a7[o + c] * pim_0 - n7_0 - n8_p;
+  if (REAL) {
+    const double *__restrict__ q1 = SNAP ? L.p1 : p;
+    const long long s = SNAP ? (long long)i * RS : o, sm = SNAP ? s - RS : om, sp = SNAP ? s + RS : op;
+    rhs = rhs - a5[o + c] * q1[sm + jp] - a5[op + jm] * q1[sp + jm] - a8[o + c] * q1[sm + jm] - a8[op + jp] * q1[sp + jp];
+  }
+  double x = rhs * bet[o + c];
+  p[o + c] = x;
+
+  // ---- k = 2 .. nz-1 (:281-291)
+  for (int k = 2; k <= nz - 1; k++) {
+    pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
+    m3_m = m3_0; m3_0 = m3_p; m4_0 = m4_p; n6_m = n6_0; n6_0 = n6_p; n7_0 = n7_p;
+    LOAD_ROW(k + 1, pjm_p, pim_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p);
+    const long long ko = o + (long long)(k - 1) * RS + c;
+    rhs = b[ko] - a3[ko] * pjm_p - m3_m - a4[ko] * pjm_0 - m4_0 - a5[ko] * pjm_m - m5_p
+                - a6[ko] * pim_p - n6_m - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m - n8_p;
+    x = (rhs - a2[ko] * x) * bet[ko];
+    p[ko] = x;
+  }
+  // ---- k = nz (:293-301)
+  {
+    pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
+    m3_m = m3_0; m4_0 = m4_p; n6_m = n6_0; n7_0 = n7_p;
+    const long long ko = o + (long long)(nz - 1) * RS + c;
+    rhs = b[ko] - m3_m - a4[ko] * pjm_0 - m4_0 - a5[ko] * pjm_m - n6_m - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m;
+    x = (rhs - a2[ko] * x) * bet[ko];
+    p[ko] = x;
+  }
+  // ---- back substitution (:330-332): xc(k) = xc(k) - gam(k+1)*xc(k+1)
+  for (int k = nz - 1; k >= 1; k--) {
+    const long long ko = o + (long long)(k - 1) * RS + c;
+    x = p[ko] - gam[ko + RS] * x;
+    p[ko] = x;
+  }
+#undef LOAD_ROW
+}
+
+// snapshot of p(k=1,:,:) for the parallel red-black pass
+__global__ void k_snapshot_k1(LevView L) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (t < L.RS) L.p1[(long long)i * L.RS + t] = L.p[(long long)i * L.plane + t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual r = b - A p on the interior and per-block partial sums of r^2.  mg_relax.f90:421-515.
+// gridDim.z = 2: z = 0 handles the odd-j half-rows, z = 1 the even-j ones.
+// ------------------------------------------------------------------------------------------------
+template <bool REAL>
+__global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict__ partial, int want_norm) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int jodd = blockIdx.z == 0;
+  double acc = 0.0;
+  if (jh < (L.ny >> 1) && i <= L.nx) {
+    int c, jm, jp;
+    if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+    else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+    const long long RS = L.RS;
+    const int nz = L.nz;
+    const double *__restrict__ p = L.p, *__restrict__ b = L.b;
+    double *__restrict__ r = L.r;
+    const double *__restrict__ a1 = L.cA[0], *__restrict__ a2 = L.cA[1], *__restrict__ a3 = L.cA[2],
+                 *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4], *__restrict__ a6 = L.cA[5],
+                 *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7];
+    const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+    double pjm_m, pjm_0, pjm_p, pim_m, pim_0, pim_p, pc_m, pc_0, pc_p, a2_0, a2_p;
+    double m3_m, m3_0, m4_0, m5_p, n6_m, n6_0, n7_0, n8_p, m3_p, m4_p, n6_p, n7_p;
+#define LOAD_ROW(q, PJM, PIM, PC, A2, M3, M4, M5, N6, N7, N8)                  \
+  {                                                                            \
+    const long long ro = (long long)((q)-1) * RS;                              \
+    PJM = p[o + ro + jm]; PIM = p[om + ro + c]; PC = p[o + ro + c]; A2 = a2[o + ro + c]; \
+    const double pj_ = p[o + ro + jp], pi_ = p[op + ro + c];                   \
+    M3 = a3[o + ro + jp] * pj_; M4 = a4[o + ro + jp] * pj_; M5 = a5[o + ro + jp] * pj_; \
+    N6 = a6[op + ro + c] * pi_; N7 = a7[op + ro + c] * pi_; N8 = a8[op + ro + c] * pi_; \
+  }
+    double dum5, dum8;
+    LOAD_ROW(1, pjm_0, pim_0, pc_0, a2_0, m3_0, m4_0, dum5, n6_0, n7_0, dum8);
+    LOAD_ROW(2, pjm_p, pim_p, pc_p, a2_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p);
+    (void)dum5; (void)dum8;
+    // k = 1 (:464-482)
+    double rr = b[o + c] - a1[o + c] * pc_0 - a2_p * pc_p - a3[o + c] * pjm_p - a4[o + c] * pjm_0 - m4_0 - m5_p
+                - a6[o + c] * pim_p - a7[o + c] * pim_0 - n7_0 - n8_p;
+    if (REAL)
+      rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
+    r[o + c] = rr;
+    acc = acc + rr * rr;
+    for (int k = 2; k <= nz - 1; k++) {  // (:484-496)
+      pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p; pc_m = pc_0; pc_0 = pc_p; a2_0 = a2_p;
+      m3_m = m3_0; m3_0 = m3_p; m4_0 = m4_p; n6_m = n6_0; n6_0 = n6_p; n7_0 = n7_p;
+      LOAD_ROW(k + 1, pjm_p, pim_p, pc_p, a2_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p);
+      const long long ko = o + (long long)(k - 1) * RS + c;
+      rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - a2_p * pc_p - a3[ko] * pjm_p - m3_m - a4[ko] * pjm_0 - m4_0
+                 - a5[ko] * pjm_m - m5_p - a6[ko] * pim_p - n6_m - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m - n8_p;
+      r[ko] = rr;
+      acc = acc + rr * rr;
+    }
+    {  // k = nz (:498-509)
+      pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p; pc_m = pc_0; pc_0 = pc_p; a2_0 = a2_p;
+      m3_m = m3_0; m4_0 = m4_p; n6_m = n6_0; n7_0 = n7_p;
+      const long long ko = o + (long long)(nz - 1) * RS + c;
+      rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - m3_m - a4[ko] * pjm_0 - m4_0 - a5[ko] * pjm_m - n6_m
+                 - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m;
+      r[ko] = rr;
+      acc = acc + rr * rr;
+    }
+#undef LOAD_ROW
+  }
+  if (!want_norm) return;
+  // block reduction: wave shuffle, then LDS across the waves of the block (deterministic order)
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double red[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6;
+  if ((tid & 63) == 0) red[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    for (int q = 0; q < nw; q++) s += red[q];
+    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// sum of squares of the interior of a JS field (bnorm of solve_p, mg_solvers.f90:50)
+__global__ __launch_bounds__(256) void k_sumsq(LevView L, const double *__restrict__ a, double *__restrict__ partial) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  double acc = 0.0;
+  if (jh < (L.ny >> 1) && i <= L.nx) {
+    const int c = blockIdx.z == 0 ? L.HO + jh : L.EO + jh + 1;
+    const long long o = (long long)i * L.plane + c;
+    for (int k = 0; k < L.nz; k++) { const double v = a[o + (long long)k * L.RS]; acc += v * v; }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double red[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6;
+  if ((tid & 63) == 0) red[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    for (int q = 0; q < nw; q++) s += red[q];
+    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// second stage: one block sums the partials in index order -> out[0]
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int n, double *__restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int q = threadIdx.x; q < n; q += 256) s += partial[q];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
+// `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst) {
+  const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
+  const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (j2 > C.ny || i2 > C.nx) return;
+  const int i = 2 * i2 - 1;
+  const int po = F.HO + (j2 - 1), pe = F.EO + j2;  // fine j = 2*j2-1 (odd) and 2*j2 (even)
+  const double *__restrict__ x = F.r;
+  const long long o0 = (long long)i * F.plane, o1 = o0 + F.plane;
+  const long long oc = (long long)i2 * C.plane + jpos(C, j2);
+  for (int k2 = 1; k2 <= C.nz; k2++) {
+    const long long r0 = (long long)(2 * k2 - 2) * F.RS, r1 = r0 + F.RS;
+    const double z = x[o0 + r0 + po] + x[o1 + r0 + po] + x[o0 + r0 + pe] + x[o1 + r0 + pe]
+                   + x[o0 + r1 + po] + x[o1 + r1 + po] + x[o0 + r1 + pe] + x[o1 + r1 + pe];
+    dst[oc + (long long)(k2 - 1) * C.RS] = z;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prolongation + correction: fine r = interp(coarse p); fine p += fine r (interior).
+// mg_intergrids.f90:366-450 (tri-linear, top level x 1/2), :336-363 (nearest), :226 (p = p + r).
+// One lane = one coarse column = 2x2 fine columns.  `src` is the coarse p (or the split block).
+// ------------------------------------------------------------------------------------------------
+template <bool LINEAR>
+__global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc) {
+  const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
+  const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (j2 > C.ny || i2 > C.nx) return;
+  const int i = 2 * i2 - 1;
+  const int po = F.HO + (j2 - 1), pe = F.EO + j2;  // fine j (odd) and j+1 (even)
+  const int c0 = jpos(C, j2), cm = jpos(C, j2 - 1), cp = jpos(C, j2 + 1);
+  const long long q0 = (long long)i2 * C.plane, qm = q0 - C.plane, qp = q0 + C.plane;
+  const long long o0 = (long long)i * F.plane, o1 = o0 + F.plane;
+  double *__restrict__ rf = F.r;
+  double *__restrict__ pf = F.p;
+  const int nz = C.nz;
+#define XC(k2, JJ, QQ) xc[QQ + (long long)((k2)-1) * C.RS + JJ]
+#define PUT(k, OO, PP, val) { const long long t_ = OO + (long long)((k)-1) * F.RS + PP; const double v_ = (val); rf[t_] = v_; pf[t_] = pf[t_] + v_; }
+  if (!LINEAR) {
+    for (int k2 = 1; k2 <= nz; k2++) {
+      const double v = XC(k2, c0, q0);
+      const int k = 2 * k2 - 1;
+      PUT(k, o0, po, v); PUT(k + 1, o0, po, v); PUT(k, o0, pe, v); PUT(k + 1, o0, pe, v);
+      PUT(k, o1, po, v); PUT(k + 1, o1, po, v); PUT(k, o1, pe, v); PUT(k + 1, o1, pe, v);
+    }
+    return;
+  }
+  const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
+  int k2 = 1;
+  PUT(1, o0, po, +a * XC(k2, c0, q0) + c * XC(k2, cm, qm) + b * XC(k2, cm, q0) + b * XC(k2, c0, qm));
+  PUT(1, o0, pe, +a * XC(k2, c0, q0) + c * XC(k2, cp, qm) + b * XC(k2, cp, q0) + b * XC(k2, c0, qm));
+  PUT(1, o1, po, +a * XC(k2, c0, q0) + c * XC(k2, cm, qp) + b * XC(k2, cm, q0) + b * XC(k2, c0, qp));
+  PUT(1, o1, pe, +a * XC(k2, c0, q0) + c * XC(k2, cp, qp) + b * XC(k2, cp, q0) + b * XC(k2, c0, qp));
+  for (int k = 2; k <= nz * 2 - 1; k++) {
+    k2 = (k + 1) / 2;
+    const int kp = k2 - ((k % 2) * 2 - 1);
+    PUT(k, o0, po, +d * XC(k2, c0, q0) + f * XC(k2, cm, qm) + e * XC(k2, cm, q0) + e * XC(k2, c0, qm)
+                   + e * XC(kp, c0, q0) + g * XC(kp, cm, qm) + f * XC(kp, cm, q0) + f * XC(kp, c0, qm));
+    PUT(k, o0, pe, +d * XC(k2, c0, q0) + f * XC(k2, cp, qm) + e * XC(k2, cp, q0) + e * XC(k2, c0, qm)
+                   + e * XC(kp, c0, q0) + g * XC(kp, cp, qm) + f * XC(kp, cp, q0) + f * XC(kp, c0, qm));
+    PUT(k, o1, po, +d * XC(k2, c0, q0) + f * XC(k2, cm, qp) + e * XC(k2, cm, q0) + e * XC(k2, c0, qp)
+                   + e * XC(kp, c0, q0) + g * XC(kp, cm, qp) + f * XC(kp, cm, q0) + f * XC(kp, c0, qp));
+    PUT(k, o1, pe, +d * XC(k2, c0, q0) + f * XC(k2, cp, qp) + e * XC(k2, cp, q0) + e * XC(k2, c0, qp)
+                   + e * XC(kp, c0, q0) + g * XC(kp, cp, qp) + f * XC(kp, cp, q0) + f * XC(kp, c0, qp));
+  }
+  const int k = nz * 2;  // top level: k2 keeps its last value (mg_intergrids.f90:434)
+  PUT(k, o0, po, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cm, qm) + b * XC(k2, cm, q0) + b * XC(k2, c0, qm)));
+  PUT(k, o0, pe, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cp, qm) + b * XC(k2, cp, q0) + b * XC(k2, c0, qm)));
+  PUT(k, o1, po, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cm, qp) + b * XC(k2, cm, q0) + b * XC(k2, c0, qp)));
+  PUT(k, o1, pe, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cp, qp) + b * XC(k2, cp, q0) + b * XC(k2, c0, qp)));
+#undef XC
+#undef PUT
+}
+
+// ------------------------------------------------------------------------------------------------
+// physical-boundary halo (homogeneous Neumann mirror), nh = 1.  mg_mpi_exchange.f90:509-537 (edges),
+// :552,567,582,597 (corners where both sides are physical).  All sources are interior cells.
+// grid: x = perimeter index, y = k.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_phys(LevView L, double *__restrict__ a, Sides ph) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ro = (long long)blockIdx.y * L.RS;
+  const int nx = L.nx, ny = L.ny;
+  if (q < nx) {  // south and north edges of plane i
+    const long long o = (long long)(q + 1) * L.plane + ro;
+    if (ph.S) a[o + jpos(L, 0)] = a[o + jpos(L, 1)];
+    if (ph.N) a[o + jpos(L, ny + 1)] = a[o + jpos(L, ny)];
+  } else if (q < nx + ny) {  // west and east planes, j = 1..ny
+    const int j = q - nx + 1, c = jpos(L, j);
+    if (ph.W) a[ro + c] = a[L.plane + ro + c];
+    if (ph.E) a[(long long)(nx + 1) * L.plane + ro + c] = a[(long long)nx * L.plane + ro + c];
+  } else if (q == nx + ny) {
+    const long long oE = (long long)(nx + 1) * L.plane + ro, oI = (long long)nx * L.plane + ro;
+    if (ph.S && ph.W) a[ro + jpos(L, 0)] = a[L.plane + ro + jpos(L, 1)];
+    if (ph.S && ph.E) a[oE + jpos(L, 0)] = a[oI + jpos(L, 1)];
+    if (ph.N && ph.E) a[oE + jpos(L, ny + 1)] = a[oI + jpos(L, ny)];
+    if (ph.N && ph.W) a[ro + jpos(L, ny + 1)] = a[L.plane + ro + jpos(L, ny)];
+  }
+}
+
+// mixed corners, after the edge halos have been received (mg_mpi_exchange.f90:720-743).
+// mode per corner (SW,SE,NE,NW): 0 nothing, 1 copy along i from the received S/N halo row, 2 copy along j
+// from the received W/E halo plane.
+__global__ void k_halo_mixed_corners(LevView L, double *__restrict__ a, int mSW, int mSE, int mNE, int mNW) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= L.nz) return;
+  const long long ro = (long long)k * L.RS;
+  const int nx = L.nx, ny = L.ny;
+  const long long W0 = ro, W1 = L.plane + ro, E0 = (long long)(nx + 1) * L.plane + ro, E1 = (long long)nx * L.plane + ro;
+  const int j0 = jpos(L, 0), j1 = jpos(L, 1), jn = jpos(L, ny), jn1 = jpos(L, ny + 1);
+  if (mSW == 1) a[W0 + j0] = a[W1 + j0]; else if (mSW == 2) a[W0 + j0] = a[W0 + j1];
+  if (mSE == 1) a[E0 + j0] = a[E1 + j0]; else if (mSE == 2) a[E0 + j0] = a[E0 + j1];
+  if (mNE == 1) a[E0 + jn1] = a[E1 + jn1]; else if (mNE == 2) a[E0 + jn1] = a[E0 + jn];
+  if (mNW == 1) a[W0 + jn1] = a[W1 + jn1]; else if (mNW == 2) a[W0 + jn1] = a[W0 + jn];
+}
+
+// pack / unpack of the 8 exchange buffers (edges nz*nx, nz*ny; corners nz).  dir: 0 S,1 E,2 N,3 W,4 SW,5 SE,6 NE,7 NW.
+// pack reads the interior edge that the neighbour in direction `dir` needs; unpack writes my halo on side `dir`.
+__global__ void k_halo_pack(LevView L, double *__restrict__ a, double *__restrict__ buf, int dir, int unpack) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  const int nx = L.nx, ny = L.ny;
+  int i, j, n;
+  switch (dir) {
+    case 0: n = nx; i = q + 1; j = unpack ? 0 : 1; break;
+    case 1: n = ny; j = q + 1; i = unpack ? nx + 1 : nx; break;
+    case 2: n = nx; i = q + 1; j = unpack ? ny + 1 : ny; break;
+    case 3: n = ny; j = q + 1; i = unpack ? 0 : 1; break;
+    case 4: n = 1; i = unpack ? 0 : 1; j = unpack ? 0 : 1; break;
+    case 5: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? 0 : 1; break;
+    case 6: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? ny + 1 : ny; break;
+    default: n = 1; i = unpack ? 0 : 1; j = unpack ? ny + 1 : ny; break;
+  }
+  if (q >= n) return;
+  const long long e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
+  const long long t = (long long)q * L.nz + k;
+  if (unpack) a[e] = buf[t]; else buf[t] = a[e];
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion between the reference layout (k,j,i) k fastest and JS.  dir 0: ref -> JS, 1: JS -> ref
+// ------------------------------------------------------------------------------------------------
+__global__ void k_convert(LevView L, double *__restrict__ js, double *__restrict__ ref, int nslot, int slot, int dir) {
+  const long long n = (long long)L.nz * (L.ny + 2) * (L.nx + 2);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % L.nz);
+  const long long ji = t / L.nz;
+  const int j = (int)(ji % (L.ny + 2)), i = (int)(ji / (L.ny + 2));
+  const long long e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
+  if (dir == 0) js[e] = ref[t * nslot + slot]; else ref[t * nslot + slot] = js[e];
+}
+
+// gather (mg_gather.f90:95-174): copy the interior of member block (l,m) (reference layout incl. halo, as received)
+// into the JS coarse b at offset (l*nxc, m*nyc)
+__global__ void k_gather_place(LevView C, double *__restrict__ dstjs, const double *__restrict__ blk, int nxc, int nyc, int l, int m) {
+  const long long n = (long long)C.nz * nyc * nxc;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % C.nz);
+  const long long ji = t / C.nz;
+  const int j = 1 + (int)(ji % nyc), i = 1 + (int)(ji / nyc);
+  const double v = blk[((long long)i * (nyc + 2) + j) * C.nz + k];
+  dstjs[(long long)(i + l * nxc) * C.plane + (long long)k * C.RS + jpos(C, j + m * nyc)] = v;
+}
+// pre-gather block (JS level view Cs of the small block) -> contiguous reference-layout block incl. halo
+__global__ void k_block_to_ref(LevView Cs, const double *__restrict__ js, double *__restrict__ blk) {
+  const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % Cs.nz);
+  const long long ji = t / Cs.nz;
+  const int j = (int)(ji % (Cs.ny + 2)), i = (int)(ji / (Cs.ny + 2));
+  blk[t] = js[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)];
+}
+// split (mg_gather.f90:177-220): own quadrant of the gathered p, halo included, into the small JS block
+__global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, double *__restrict__ dst, int l, int m) {
+  const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % Cs.nz);
+  const long long ji = t / Cs.nz;
+  const int j = (int)(ji % (Cs.ny + 2)), i = (int)(ji / (Cs.ny + 2));
+  dst[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)] =
+      pc[(long long)(i + l * Cs.nx) * C.plane + (long long)k * C.RS + jpos(C, j + m * Cs.ny)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------------
+static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
+
+extern "C" {
+
+void mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap) {
+  dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, nplanes);
+  if (real && snap) hipLaunchKernelGGL((k_relax_colour<true, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
+  else if (real) hipLaunchKernelGGL((k_relax_colour<true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
+  else hipLaunchKernelGGL((k_relax_colour<false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
+}
+void mgxk_snapshot_k1(hipStream_t st, const LevView *L) {
+  hipLaunchKernelGGL(k_snapshot_k1, dim3((L->RS + 255) / 256, L->nx + 2), dim3(256), 0, st, *L);
+}
+int mgxk_residual_nblocks(const LevView *L) { dim3 g = col_grid(L->ny / 2, L->nx, 2); return g.x * g.y * g.z; }
+void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *out, int real, int want_norm) {
+  dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
+  if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm);
+  else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm);
+  if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
+}
+void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *partial, double *out) {
+  dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
+  hipLaunchKernelGGL(k_sumsq, grd, blk, 0, st, *L, a, partial);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
+}
+void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst) {
+  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst);
+}
+void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear) {
+  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, src);
+  else hipLaunchKernelGGL((k_coarse2fine<false>), col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, src);
+}
+void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
+  const int n = L->nx + L->ny + 1;
+  hipLaunchKernelGGL(k_halo_phys, dim3((n + 255) / 256, L->nz), dim3(256), 0, st, *L, a, ph);
+}
+void mgxk_halo_mixed_corners(hipStream_t st, const LevView *L, double *a, int mSW, int mSE, int mNE, int mNW) {
+  hipLaunchKernelGGL(k_halo_mixed_corners, dim3((L->nz + 63) / 64), dim3(64), 0, st, *L, a, mSW, mSE, mNE, mNW);
+}
+void mgxk_halo_pack(hipStream_t st, const LevView *L, double *a, double *buf, int dir, int unpack) {
+  const int n = (dir == 0 || dir == 2) ? L->nx : ((dir == 1 || dir == 3) ? L->ny : 1);
+  hipLaunchKernelGGL(k_halo_pack, dim3((n + 63) / 64, L->nz), dim3(64), 0, st, *L, a, buf, dir, unpack);
+}
+void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
+  const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
+  hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *L, js, ref, nslot, slot, dir);
+}
+void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m) {
+  const long long n = (long long)C->nz * nyc * nxc;
+  hipLaunchKernelGGL(k_gather_place, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *C, dstjs, blk, nxc, nyc, l, m);
+}
+void mgxk_block_to_ref(hipStream_t st, const LevView *Cs, const double *js, double *blk) {
+  const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
+  hipLaunchKernelGGL(k_block_to_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *Cs, js, blk);
+}
+void mgxk_split(hipStream_t st, const LevView *C, const LevView *Cs, const double *pc, double *dst, int l, int m) {
+  const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
+  hipLaunchKernelGGL(k_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *C, *Cs, pc, dst, l, m);
+}
+
+}  // extern "C"

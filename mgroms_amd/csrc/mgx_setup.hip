@@ -1,0 +1,406 @@
+// Set-up kernels (run once per geometry): coarsening of the 2-D geometry, sigma-coordinate depths,
+// the 8 stored coefficients per cell, the tridiagonal pivots; plus compute_rhs / correct_uvw on the
+// model's (i,j,k)-ordered velocities.  These work in the reference (Fortran) layout; the coefficients
+// are then repacked into the solver's JS layout (mgx_kernels.hip:k_convert).  One lane = one (j,i) column.
+// Operation order follows the reference line by line (compiled with -ffp-contract=off).
+#include "mgx_internal.h"
+
+#define ZR(k, j, i) G.zr[(((long long)((i) + 1)) * (ny + 4) + ((j) + 1)) * nz + ((k)-1)]
+#define ZW(k, j, i) G.zw[(((long long)((i) + 1)) * (ny + 4) + ((j) + 1)) * (nz + 1) + ((k)-1)]
+#define A2(a, j, i) a[((long long)(i)) * (ny + 2) + (j)]
+#define DX(j, i) A2(G.dx, j, i)
+#define DY(j, i) A2(G.dy, j, i)
+#define I3(k, j, i) ((((long long)(i)) * (ny + 2) + (j)) * nz + ((k)-1))
+#define I3P(k, j, i) ((((long long)(i)) * (ny + 2) + (j)) * (nz + 1) + ((k)-1))
+#define CW(k, j, i) G.cw[I3P(k, j, i)]
+#define CA(s, k, j, i) G.cA[I3(k, j, i) * 8 + ((s)-1)]
+
+#define COLUMN_THREAD(jlo, jhi, ilo, ihi)                                     \
+  const int j = (jlo) + blockIdx.x * blockDim.x + threadIdx.x;                \
+  const int i = (ilo) + blockIdx.y * blockDim.y + threadIdx.y;                \
+  if (j > (jhi) || i > (ihi)) return;                                         \
+  const int nx = G.nx, ny = G.ny, nz = G.nz;                                  \
+  (void)nx; (void)ny; (void)nz;
+
+// mg_define_matrix.f90:116-138: dx,dy = 1/2 sum4 ; zeta,h = 1/4 sum4.  dst is (0:nyc+1,0:nxc+1)
+__global__ void k_coarsen2d(const double *__restrict__ src, double *__restrict__ dst, int nyf, int nyc, int nxc, double fac) {
+  const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (j > nyc || i > nxc) return;
+  const int fj = 2 * j - 1, fi = 2 * i - 1;
+  const long long sf = nyf + 2;
+  dst[(long long)i * (nyc + 2) + j] = fac * (src[fi * sf + fj] + src[fi * sf + fj + 1] + src[(fi + 1) * sf + fj] + src[(fi + 1) * sf + fj + 1]);
+}
+
+// generic rectangle operation on a reference-layout array a(nzz, 1-nh:ny+nh, 1-nh:nx+nh):
+//   op 0: a(dst) = a(src)                    src_j = mj ? cj - j : j + cj ; src_i likewise
+//   op 1: a(dst) = 2*a(src) - a(src2)        (nh=2 extrapolation, mg_mpi_exchange.f90:956-964)
+//   op 2: a(dst) = 0
+//   op 3: buf = a(dst rect)  (pack)          op 4: a(dst rect) = buf (unpack); buffer order (k fastest, then j, then i)
+struct RectOp { int op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, mi2, ci2; };
+__global__ void k_rect(double *__restrict__ a, double *__restrict__ buf, RectOp R) {
+  const long long nj = R.j1 - R.j0 + 1, ni = R.i1 - R.i0 + 1, n = nj * ni * R.nzz;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % R.nzz);
+  const int j = R.j0 + (int)((t / R.nzz) % nj), i = R.i0 + (int)(t / (R.nzz * nj));
+  const long long sj = R.ny + 2 * R.nh;
+#define AI(jj, ii) (((long long)((ii) + R.nh - 1)) * sj + ((jj) + R.nh - 1)) * R.nzz + k
+  const long long d = AI(j, i);
+  if (R.op == 2) { a[d] = 0.0; return; }
+  if (R.op == 3) { buf[t] = a[d]; return; }
+  if (R.op == 4) { a[d] = buf[t]; return; }
+  const int sjj = R.mj ? R.cj - j : j + R.cj, sii = R.mi ? R.ci - i : i + R.ci;
+  if (R.op == 0) { a[d] = a[AI(sjj, sii)]; return; }
+  const int sj2 = R.mj2 ? R.cj2 - j : j + R.cj2, si2 = R.mi2 ? R.ci2 - i : i + R.ci2;
+  a[d] = 2.0 * a[AI(sjj, sii)] - a[AI(sj2, si2)];
+#undef AI
+}
+
+// mg_zr_zw.f90:98-170 setup_zr_zw_croco, 'new_s_coord', computed on 0:n+1 (:91)
+__global__ void k_zr_zw(GeoView G, double hlim, double theta_b, double theta_s) {
+  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  const double one = 1.0, hlf = 0.5, nul = 0.0;
+  const double cff = one / (double)nz;
+  const double h = A2(G.h, j, i), zeta = A2(G.zeta, j, i);
+  const double hinv = one / (h + hlim);
+  for (int k = 1; k <= nz + 1; k++) {
+    double cswf, cs_w;
+    const double sc_w = cff * (double)(k - 1 - nz);
+    if (theta_s > nul) cswf = (one - cosh(theta_s * sc_w)) / (cosh(theta_s) - one); else cswf = -(sc_w * sc_w);
+    if (theta_b > nul) cs_w = (exp(theta_b * cswf) - one) / (one - exp(-theta_b)); else cs_w = cswf;
+    const double cff_w = hlim * sc_w;
+    const double z_w0 = cff_w + cs_w * h;
+    ZW(k, j, i) = z_w0 * h * hinv + zeta * (1. + z_w0 * hinv);
+    if (k <= nz) {
+      double csrf, cs_r;
+      const double sc_r = cff * ((double)(k - nz) - hlf);
+      if (theta_s > nul) csrf = (one - cosh(theta_s * sc_r)) / (cosh(theta_s) - one); else csrf = -(sc_r * sc_r);
+      if (theta_b > nul) cs_r = (exp(theta_b * csrf) - one) / (one - exp(-theta_b)); else cs_r = csrf;
+      const double cff_r = hlim * sc_r;
+      const double z_r0 = cff_r + cs_r * h;
+      ZR(k, j, i) = z_r0 * h * hinv + zeta * (1. + z_r0 * hinv);
+    }
+  }
+}
+
+// mg_define_matrix.f90:283-336: dzw, zxdy, zydx (level 1) and cw, on 0:n+1
+__global__ void k_cw(GeoView G, int lev1) {
+  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  const double one = 1.0, hlf = 0.5;
+  if (lev1) {
+    G.dzw[I3P(1, j, i)] = ZR(1, j, i) - ZW(1, j, i);
+    for (int k = 2; k <= nz; k++) G.dzw[I3P(k, j, i)] = ZR(k, j, i) - ZR(k - 1, j, i);
+    G.dzw[I3P(nz + 1, j, i)] = ZW(nz + 1, j, i) - ZR(nz, j, i);
+    for (int k = 1; k <= nz; k++) {
+      G.zydx[I3(k, j, i)] = hlf * ((ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
+      G.zxdy[I3(k, j, i)] = hlf * ((ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
+    }
+  }
+  const double Arz = DX(j, i) * DY(j, i);
+  for (int k = 1; k <= nz + 1; k++) {
+    const double sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
+    const double sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
+    const double den = (k == 1) ? (ZR(k, j, i) - ZW(k, j, i)) : ((k == nz + 1) ? (ZW(k, j, i) - ZR(k - 1, j, i)) : (ZR(k, j, i) - ZR(k - 1, j, i)));
+    CW(k, j, i) = (Arz / den) * (one + sx * sx + sy * sy);
+  }
+}
+
+// mg_define_matrix.f90:352-609: off-diagonal slots (bmask = .false., umask = vmask = 1).
+// Loop ranges of the reference: slots 3,4,5(k>1): i=1..nx, j=1..ny+1 ; slots 6,7,8(k>1): i=1..nx+1, j=1..ny ;
+// cA(5,1): i=1..nx+1, j=0..ny ; cA(8,1): i=1..nx+1, j=1..ny+1 ; cA(2): interior.
+__global__ void k_cA_offdiag(GeoView G) {
+  COLUMN_THREAD(0, G.ny + 1, 1, G.nx + 1)
+  const double one = 1.0, qrt = 0.25, hlf = 0.5;
+  const bool in345 = (i <= nx) && (j >= 1);
+  const bool in678 = (j >= 1) && (j <= ny);
+  int k = 1;
+  if (in345) {
+    CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
+                            (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+    const double t1 = ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+    const double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i));
+    CA(4, k, j, i) =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i))) /
+            (hlf * (DY(j, i) + DY(j - 1, i)))
+        - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)))
+        - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i) -
+                 (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+  }
+  if (in678) {
+    CA(6, k, j, i) = qrt * ((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i) +
+                            (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * one;
+    const double t1 = ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+    const double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1));
+    CA(7, k, j, i) =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1))) /
+            (hlf * (DX(j, i) + DX(j, i - 1)))
+        - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)))
+        - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1) -
+                 (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+  }
+  if (j <= ny) {
+    CA(5, k, j, i) =
+        +hlf * ((hlf * (ZR(k, j + 1, i + 1) - ZR(k, j + 1, i - 1)) / DX(j + 1, i)) * DY(j + 1, i)) *
+                ((hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)) /
+                (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * one * one
+        + hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+  }
+  if (j >= 1) {
+    CA(8, k, j, i) =
+        -hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
+                ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
+                (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * one * one
+        - hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+  }
+  for (k = 2; k <= nz - 1; k++) {
+    if (in345 && j <= ny) CA(2, k, j, i) = CW(k, j, i);
+    if (in345) {
+      CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
+                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+      CA(4, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) *
+                        (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * one;
+      CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
+                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+    }
+    if (in678) {
+      CA(6, k, j, i) = qrt * (((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                              ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+      CA(7, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) *
+                        (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * one;
+      CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+    }
+  }
+  k = nz;
+  if (in345 && j <= ny) CA(2, k, j, i) = CW(k, j, i);
+  if (in345) {
+    CA(4, k, j, i) =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) /
+             (hlf * (DY(j, i) + DY(j - 1, i)))
+         + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))
+                  + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * one;
+    CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
+                             ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+  }
+  if (in678) {
+    CA(7, k, j, i) =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) /
+             (hlf * (DX(j, i) + DX(j, i - 1)))
+         + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))
+                  + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * one;
+    CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
+                             ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+  }
+}
+
+// mg_define_matrix.f90:616-657: diagonal, interior columns
+__global__ void k_cA_diag(GeoView G) {
+  COLUMN_THREAD(1, G.ny, 1, G.nx)
+  const double hlf = 0.5;
+  int k = 1;
+  CA(1, k, j, i) = -CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
+                   - CA(6, k, j, i) - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(5, k + 1, j + 1, i)
+                   - CA(5, k, j, i) - CA(5, k, j - 1, i + 1) - CA(8, k, j, i) - CA(8, k, j + 1, i + 1);
+  for (k = 2; k <= nz - 1; k++)
+    CA(1, k, j, i) = -CA(2, k, j, i) - CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i)
+                     - CA(7, k, j, i + 1) - CA(6, k, j, i) - CA(6, k - 1, j, i + 1) - CA(8, k, j, i)
+                     - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i)
+                     - CA(5, k + 1, j + 1, i);
+  k = nz;
+  CA(1, k, j, i) = -CA(2, k, j, i) - CW(k + 1, j, i)
+                   + hlf * (hlf * (ZR(k, j, i + 2) - ZR(k, j, i)) / DX(j, i + 1)) * DY(j, i + 1)
+                   - hlf * (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)
+                   + hlf * (hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)
+                   - hlf * (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)
+                   - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
+                   - CA(6, k - 1, j, i + 1) - CA(8, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i);
+}
+
+// tridiagonal pivots of every interior column (mg_relax.f90:322-327): bet(1)=1/d(1);
+// gam(k)=dd(k-1)*bet ; bet(k)=1/(d(k)-dd(k-1)*gam(k)) with d=cA(1,:), dd(k-1)=cA(2,k)
+__global__ void k_pivots(LevView L) {
+  const int jj = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (jj > L.ny || i > L.nx) return;
+  const long long o = (long long)i * L.plane + jpos(L, jj);
+  const double *__restrict__ d = L.cA[0], *__restrict__ dd = L.cA[1];
+  double bet = 1.0 / d[o];
+  L.bet[o] = bet;
+  L.gam[o] = 0.0;
+  for (int k = 2; k <= L.nz; k++) {
+    const long long ko = o + (long long)(k - 1) * L.RS;
+    const double g = dd[ko] * bet;
+    bet = 1.0 / (d[ko] - dd[ko] * g);
+    L.gam[ko] = g;
+    L.bet[ko] = bet;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compute_rhs (mg_compute_rhs.f90:14-379, bmask = .false.) on level 1.  u,v,w are the model's
+// (i,j,k)-ordered arrays on the device; uf/vf share `fx` (nz,0:ny+1,0:nx+1), wf is `fz` (nz+1,..).
+// ------------------------------------------------------------------------------------------------
+struct ModelView { double *u, *v, *w, *rmask; };
+#define U(i, j, k) M.u[(((long long)((k)-1)) * (ny + 2) + (j)) * (nx + 1) + ((i)-1)]
+#define V(i, j, k) M.v[(((long long)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
+#define Wv(i, j, k) M.w[(((long long)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
+#define RM(j, i) (M.rmask ? A2(M.rmask, j, i) : 1.0)
+#define DZW(k, j, i) G.dzw[I3P(k, j, i)]
+#define ZXDY(k, j, i) G.zxdy[I3(k, j, i)]
+#define ZYDX(k, j, i) G.zydx[I3(k, j, i)]
+
+__global__ void k_rhs_uf(GeoView G, ModelView M, double *__restrict__ fx) {
+  COLUMN_THREAD(1, G.ny, 1, G.nx + 1)
+  const double two = 2.0, hlf = 0.5, qrt = 0.25;
+  int k = 1;
+  fx[I3(k, j, i)] =
+      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+       - qrt * (+ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))
+       - (+ZXDY(k, j, i) * ZXDY(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
+          ZXDY(k, j, i - 1) * ZXDY(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1))) *
+             (hlf * (DX(j, i) + DX(j, i - 1))) * U(i, j, k)
+       - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
+              (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0) +
+          ZXDY(k, j, i - 1) * ZYDX(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * hlf *
+              (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * 1.0 +
+               hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * 1.0))) * 1.0;
+  for (k = 2; k <= nz - 1; k++)
+    fx[I3(k, j, i)] =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+         - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                  ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                  ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
+                  ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+  k = nz;
+  fx[I3(k, j, i)] =
+      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
+       - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                ZXDY(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
+                ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+}
+
+__global__ void k_rhs_vf(GeoView G, ModelView M, double *__restrict__ fx) {
+  COLUMN_THREAD(1, G.ny + 1, 1, G.nx)
+  const double two = 2.0, hlf = 0.5, qrt = 0.25;
+  int k = 1;
+  fx[I3(k, j, i)] =
+      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+       - qrt * (+ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))
+       - (+ZYDX(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
+          ZYDX(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i))) *
+             hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k)
+       - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
+              (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0) +
+          ZXDY(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * hlf *
+              (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * 1.0 +
+               hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * 1.0))) * 1.0;
+  for (k = 2; k <= nz - 1; k++)
+    fx[I3(k, j, i)] =
+        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+         - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                  ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                  ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
+                  ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+  k = nz;
+  fx[I3(k, j, i)] =
+      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
+       - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
+                ZYDX(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
+                ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
+                ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+}
+
+__global__ void k_rhs_wf(GeoView G, ModelView M, double *__restrict__ fz) {
+  COLUMN_THREAD(1, G.ny, 1, G.nx)
+  const double hlf = 0.5, qrt = 0.25;
+  fz[I3P(1, j, i)] = 0.0;
+  for (int k = 2; k <= nz; k++) {
+    double t = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
+               qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 +
+                            ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0 +
+                            ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
+                            ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0);
+    t = t - qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 +
+                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0 +
+                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
+                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+    fz[I3P(k, j, i)] = t;
+  }
+  const int k = nz + 1;
+  fz[I3P(k, j, i)] = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
+                     hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
+                                  ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0) -
+                     hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
+                                  ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+}
+
+// rhs accumulation into the JS field b of level 1: mode 0: b = fx(i+1)-fx(i) ; 1: b += fx(j+1)-fx(j) ; 2: b += fz(k+1)-fz(k)
+__global__ void k_rhs_accum(GeoView G, LevView L, const double *__restrict__ f, int mode) {
+  COLUMN_THREAD(1, G.ny, 1, G.nx)
+  const long long o = (long long)i * L.plane + jpos(L, j);
+  for (int k = 1; k <= nz; k++) {
+    const long long e = o + (long long)(k - 1) * L.RS;
+    if (mode == 0) L.b[e] = f[I3(k, j, i + 1)] - f[I3(k, j, i)];
+    else if (mode == 1) L.b[e] = L.b[e] + f[I3(k, j + 1, i)] - f[I3(k, j, i)];
+    else L.b[e] = L.b[e] + f[I3P(k + 1, j, i)] - f[I3P(k, j, i)];
+  }
+}
+
+// correct_uvw (mg_correct_uvw.f90:73-108); p is read from the JS field of level 1
+__global__ void k_correct_uvw(GeoView G, LevView L, ModelView M) {
+  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  const double one = 1.0, hlf = 0.5;
+  const double *__restrict__ p = L.p;
+#define PJS(k, jj, ii) p[(long long)(ii)*L.plane + (long long)((k)-1) * L.RS + jpos(L, jj)]
+  if (i >= 1) {
+    const double dxu = hlf * (DX(j, i) + DX(j, i - 1));
+    for (int k = 1; k <= nz; k++) U(i, j, k) = U(i, j, k) - one / dxu * (PJS(k, j, i) - PJS(k, j, i - 1)) * 1.0;
+  }
+  if (j >= 1) {
+    const double dyv = hlf * (DY(j, i) + DY(j - 1, i));
+    for (int k = 1; k <= nz; k++) V(i, j, k) = V(i, j, k) - one / dyv * (PJS(k, j, i) - PJS(k, j - 1, i)) * 1.0;
+  }
+  for (int k = 2; k <= nz; k++) {
+    const double dzw = ZR(k, j, i) - ZR(k - 1, j, i);
+    Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (PJS(k, j, i) - PJS(k - 1, j, i));
+  }
+  const int k = nz + 1;
+  const double dzw = ZW(nz + 1, j, i) - ZR(nz, j, i);
+  Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (-PJS(k - 1, j, i));
+#undef PJS
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline dim3 cgrid(int nj, int ni) { return dim3((nj + 63) / 64, (ni + 3) / 4); }
+static const dim3 CBLK(64, 4);
+
+extern "C" {
+void mgxs_coarsen2d(hipStream_t st, const double *src, double *dst, int nyf, int nyc, int nxc, double fac) {
+  hipLaunchKernelGGL(k_coarsen2d, cgrid(nyc, nxc), CBLK, 0, st, src, dst, nyf, nyc, nxc, fac);
+}
+void mgxs_rect(hipStream_t st, double *a, double *buf, const RectOp *R) {
+  const long long n = (long long)(R->j1 - R->j0 + 1) * (R->i1 - R->i0 + 1) * R->nzz;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_rect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, buf, *R);
+}
+void mgxs_zr_zw(hipStream_t st, const GeoView *G, double hlim, double theta_b, double theta_s) {
+  hipLaunchKernelGGL(k_zr_zw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, hlim, theta_b, theta_s);
+}
+void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1) {
+  hipLaunchKernelGGL(k_cw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, lev1);
+  hipLaunchKernelGGL(k_cA_offdiag, cgrid(G->ny + 2, G->nx + 1), CBLK, 0, st, *G);
+  hipLaunchKernelGGL(k_cA_diag, cgrid(G->ny, G->nx), CBLK, 0, st, *G);
+}
+void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
+void mgxs_rhs_uf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_uf, cgrid(G->ny, G->nx + 1), CBLK, 0, st, *G, *M, fx); }
+void mgxs_rhs_vf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_vf, cgrid(G->ny + 1, G->nx), CBLK, 0, st, *G, *M, fx); }
+void mgxs_rhs_wf(hipStream_t st, const GeoView *G, const ModelView *M, double *fz) { hipLaunchKernelGGL(k_rhs_wf, cgrid(G->ny, G->nx), CBLK, 0, st, *G, *M, fz); }
+void mgxs_rhs_accum(hipStream_t st, const GeoView *G, const LevView *L, const double *f, int mode) { hipLaunchKernelGGL(k_rhs_accum, cgrid(G->ny, G->nx), CBLK, 0, st, *G, *L, f, mode); }
+void mgxs_correct_uvw(hipStream_t st, const GeoView *G, const LevView *L, const ModelView *M) { hipLaunchKernelGGL(k_correct_uvw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L, *M); }
+}
