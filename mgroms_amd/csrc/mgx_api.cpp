@@ -25,7 +25,7 @@ struct RectOp { int op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, m
 struct ModelView { double *u, *v, *w, *rmask; };
 
 extern "C" {
-void mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int);
+int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int);
@@ -178,11 +178,11 @@ int exchange(int n, const int *peer, double *const *sb, double *const *rb, const
 }
 
 // fill_halo_3D_relax / fill_halo_3D for the JS fields p,b,r (nh = 1): mg_mpi_exchange.f90:396-745
-int fill_halo_js(Level &L, double *a) {
+int fill_halo_js(Level &L, double *a, bool phys_done = false) {
   S.n_halo++;
   const int *nb = L.neighb;
   Sides ph = {nb[0] < 0, nb[1] < 0, nb[2] < 0, nb[3] < 0};
-  if (ph.S || ph.E || ph.N || ph.W) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
+  if (!phys_done && (ph.S || ph.E || ph.N || ph.W)) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
   int n = 0, peer[8], cnt[8], dirs[8];
   double *sb[8], *rb[8];
   for (int d = 0; d < 8; d++) {
@@ -291,18 +291,19 @@ int relax(int lev, int nsweeps) {
   Level &L = S.lev[lev - 1];
   if (S.method == M_GS)
     return fail("relax_method='GS' is a sequential lexicographic sweep (mg_relax.f90:131-144); this build runs the parallel orderings 'RB' and 'FC' only");
+  const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   for (int it = 1; it <= nsweeps; it++) {
     if (S.method == M_RB) {
       for (int rb = 1; rb <= 2; rb++) {
         if (S.real) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
-        mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real); S.n_launch++;
-        CHK(fill_halo_js(L, L.v.p));
+        const int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
+        CHK(fill_halo_js(L, L.v.p, fused));
       }
     } else {
       for (int fc1 = 1; fc1 <= 2; fc1++)
         for (int fc2 = 1; fc2 <= 2; fc2++) {
-          mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0); S.n_launch++;
-          CHK(fill_halo_js(L, L.v.p));
+          const int fused = mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0, ph); S.n_launch++;
+          CHK(fill_halo_js(L, L.v.p, fused));
         }
     }
   }

@@ -93,6 +93,130 @@ __global__ __launch_bounds__(256) void k_relax_colour(LevView L, int i0, int ist
 #undef LOAD_ROW
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Register-resident variant of the colour pass for nz in {2,...,64} (level 1 of the 512x512x64 problem
+// is NZ=64).  One wave = 64 columns; a colour of a 512^2 level is only 1024 waves (1 per SIMD), so the
+// kernel is written for ONE wave per SIMD and spends its 512-VGPR budget on memory-level parallelism:
+//   * the k loop is fully unrolled and software-pipelined: raw neighbour/own rows are loaded D rows ahead
+//     into register rings, so ~D*19 independent 512-byte loads are in flight per wave;
+//   * the forward solution x(k) and the back-substitution factors gam(k) stay in registers: p is written
+//     once (no forward store + backward re-read), and the backward sweep does no dependent loads;
+//   * physical-boundary mirrors of the updated columns (mg_mpi_exchange.f90:509-537,552-597) are stored by
+//     the lane that owns the column, which removes the separate halo kernel after every colour.
+// Arithmetic and its order are identical to k_relax_colour (bit-identical results).
+// ------------------------------------------------------------------------------------------------
+template <int NZ, bool REAL, bool SNAP, int D>
+__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int ipl = blockIdx.y;
+  if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
+  const int i = i0 + istep * ipl;
+  const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  int c, jm, jp;
+  if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+  else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+  const long long RS = L.RS;
+  double *__restrict__ p = L.p;
+  const double *__restrict__ b = L.b;
+  const double *__restrict__ a2 = L.cA[1], *__restrict__ a3 = L.cA[2], *__restrict__ a4 = L.cA[3],
+               *__restrict__ a5 = L.cA[4], *__restrict__ a6 = L.cA[5], *__restrict__ a7 = L.cA[6],
+               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ gam = L.gam;
+  const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+
+  constexpr int RN = D + 1;  // raw neighbour rows in flight
+  constexpr int RO = D + 1;  // raw own rows in flight
+  double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_a3[RN], r_a4[RN], r_a5[RN], r_a6[RN], r_a7[RN], r_a8[RN];
+  double o_b[RO], o_a2[RO], o_a3[RO], o_a4[RO], o_a5[RO], o_a6[RO], o_a7[RO], o_a8[RO], o_bet[RO];
+  double x[NZ], g[NZ];
+
+#define NB_LOAD(q)                                                               \
+  if ((q) <= NZ) {                                                               \
+    const long long ro_ = (long long)((q)-1) * RS; const int s_ = (q) % RN;      \
+    r_pjm[s_] = p[o + ro_ + jm]; r_pim[s_] = p[om + ro_ + c];                    \
+    r_pjp[s_] = p[o + ro_ + jp]; r_pip[s_] = p[op + ro_ + c];                    \
+    r_a3[s_] = a3[o + ro_ + jp]; r_a4[s_] = a4[o + ro_ + jp]; r_a5[s_] = a5[o + ro_ + jp]; \
+    r_a6[s_] = a6[op + ro_ + c]; r_a7[s_] = a7[op + ro_ + c]; r_a8[s_] = a8[op + ro_ + c]; \
+  }
+#define OW_LOAD(q)                                                               \
+  if ((q) <= NZ) {                                                               \
+    const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
+    o_b[s_] = b[ko_]; o_a2[s_] = a2[ko_]; o_a3[s_] = a3[ko_]; o_a4[s_] = a4[ko_]; o_a5[s_] = a5[ko_]; \
+    o_a6[s_] = a6[ko_]; o_a7[s_] = a7[ko_]; o_a8[s_] = a8[ko_]; o_bet[s_] = bet[ko_]; g[(q)-1] = gam[ko_]; \
+  }
+  // products of a raw neighbour row (computed when the row is first needed)
+#define NB_USE(q, PJM, PIM, M3, M4, M5, N6, N7, N8)                              \
+  { const int s_ = (q) % RN; PJM = r_pjm[s_]; PIM = r_pim[s_];                   \
+    M3 = r_a3[s_] * r_pjp[s_]; M4 = r_a4[s_] * r_pjp[s_]; M5 = r_a5[s_] * r_pjp[s_]; \
+    N6 = r_a6[s_] * r_pip[s_]; N7 = r_a7[s_] * r_pip[s_]; N8 = r_a8[s_] * r_pip[s_]; }
+
+  // k = 1 horizontal-diagonal terms (issued first: independent of everything else)
+  double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+  if (REAL) {
+    const double *__restrict__ q1 = SNAP ? L.p1 : p;
+    const long long s = SNAP ? (long long)i * RS : o, sm = SNAP ? s - RS : om, sp = SNAP ? s + RS : op;
+    d1 = q1[sm + jp]; d2 = q1[sp + jm]; d3 = q1[sm + jm]; d4 = q1[sp + jp];
+    e1 = a5[o + c]; e2 = a5[op + jm]; e3 = a8[o + c]; e4 = a8[op + jp];
+  }
+  // prologue: neighbour rows 1..1+D... and own rows 1..D
+#pragma unroll
+  for (int q = 1; q <= 1 + D; q++) { NB_LOAD(q) }
+#pragma unroll
+  for (int q = 1; q <= D; q++) { OW_LOAD(q) }
+
+  double pjm_m = 0, pjm_0, pjm_p, pim_m = 0, pim_0, pim_p;
+  double m3_m = 0, m3_0, m4_0, m5_p, n6_m = 0, n6_0, n7_0, n8_p, m3_p, m4_p, n6_p, n7_p, dum5, dum8;
+  NB_USE(1, pjm_0, pim_0, m3_0, m4_0, dum5, n6_0, n7_0, dum8)
+  (void)dum5; (void)dum8;
+  double xv = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) {
+    // keep the pipeline full
+    NB_LOAD(k + 1 + D)
+    OW_LOAD(k + D)
+    if (k < NZ) { NB_USE(k + 1, pjm_p, pim_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p) }
+    const int s = k % RO;
+    double rhs;
+    if (k == 1) {
+      rhs = o_b[s] - o_a3[s] * pjm_p - o_a4[s] * pjm_0 - m4_0 - m5_p - o_a6[s] * pim_p - o_a7[s] * pim_0 - n7_0 - n8_p;
+      if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4;
+      xv = rhs * o_bet[s];
+    } else if (k < NZ) {
+      rhs = o_b[s] - o_a3[s] * pjm_p - m3_m - o_a4[s] * pjm_0 - m4_0 - o_a5[s] * pjm_m - m5_p
+                   - o_a6[s] * pim_p - n6_m - o_a7[s] * pim_0 - n7_0 - o_a8[s] * pim_m - n8_p;
+      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+    } else {
+      rhs = o_b[s] - m3_m - o_a4[s] * pjm_0 - m4_0 - o_a5[s] * pjm_m - n6_m - o_a7[s] * pim_0 - n7_0 - o_a8[s] * pim_m;
+      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+    }
+    x[k - 1] = xv;
+    // rotate the three-row window
+    pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
+    m3_m = m3_0; m3_0 = m3_p; m4_0 = m4_p; n6_m = n6_0; n6_0 = n6_p; n7_0 = n7_p;
+  }
+  // back substitution in registers, then one store per cell (+ mirrors on physical boundaries)
+#pragma unroll
+  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
+
+  const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
+  const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  const int cS = L.EO, cN = jpos(L, L.ny + 1);
+  const long long oW = 0, oE = (long long)(L.nx + 1) * L.plane;
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) {
+    const long long ro = (long long)(k - 1) * RS;
+    const double v = x[k - 1];
+    p[o + ro + c] = v;
+    if (mS) p[o + ro + cS] = v;
+    if (mN) p[o + ro + cN] = v;
+    if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
+    if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
+  }
+#undef NB_LOAD
+#undef OW_LOAD
+#undef NB_USE
+}
+
 // snapshot of p(k=1,:,:) for the parallel red-black pass
 __global__ void k_snapshot_k1(LevView L) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,13 +535,33 @@ __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, do
 // ------------------------------------------------------------------------------------------------
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
 
+template <int NZ>
+static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+  dim3 blk(WAVE), grd((L->ny / 2 + WAVE - 1) / WAVE, nplanes);
+  constexpr int D = NZ >= 8 ? 3 : 1;
+  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+}
+
 extern "C" {
 
-void mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap) {
+// returns 1 when the launched kernel also wrote the physical-boundary mirrors of p (no k_halo_phys needed)
+int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+  switch (L->nz) {
+    case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 4: launch_relax_nz<4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 8: launch_relax_nz<8>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 16: launch_relax_nz<16>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 32: launch_relax_nz<32>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 64: launch_relax_nz<64>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    default: break;
+  }
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, nplanes);
   if (real && snap) hipLaunchKernelGGL((k_relax_colour<true, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
   else if (real) hipLaunchKernelGGL((k_relax_colour<true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
   else hipLaunchKernelGGL((k_relax_colour<false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
+  return 0;
 }
 void mgxk_snapshot_k1(hipStream_t st, const LevView *L) {
   hipLaunchKernelGGL(k_snapshot_k1, dim3((L->RS + 255) / 256, L->nx + 2), dim3(256), 0, st, *L);
