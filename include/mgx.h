@@ -87,6 +87,10 @@ int mgx_nlevs(void);
 int mgx_level_dims(int lev, int *nx, int *ny, int *nz);
 /* out[0..9] = npx,npy,incx,incy,gather,ngx,ngy,key,color,0 ; out[10..17] = neighbours S,E,N,W,SW,SE,NE,NW (-1 = none) */
 int mgx_level_info(int lev, int *out);
+/* Pure host logic of find_grid_levels / define_grid_dims / define_neighbours / define_gather_informations
+ * (mg_grids.f90:468-738) for any rank, usable before mgx_init and without a GPU.  out: 20 ints per level =
+ * nx,ny,nz,npx,npy,incx,incy,gather,ngx,ngy,key,color, neighbours S,E,N,W,SW,SE,NE,NW.  Returns nlevs, or -1. */
+int mgx_level_table(int nx, int ny, int nz, int npx, int npy, int rank, int nsmall, int maxlev, int *out);
 int mgx_get_field(int lev, int field, double *host);
 int mgx_set_field(int lev, int field, const double *host);
 

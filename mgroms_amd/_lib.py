@@ -45,6 +45,7 @@ _SIGS = {
     "mgx_nlevs": (C.c_int, []),
     "mgx_level_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgx_level_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "mgx_level_table": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_int)]),
     "mgx_get_field": (C.c_int, [C.c_int, C.c_int, _DP]),
     "mgx_set_field": (C.c_int, [C.c_int, C.c_int, _DP]),
     "mgx_set_comm": (C.c_int, [EXCHANGE_FN, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p]),

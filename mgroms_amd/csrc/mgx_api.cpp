@@ -130,15 +130,15 @@ int find_grid_levels(int npxg, int npyg, int nx, int ny, int nz) {
 }
 
 // level table of an arbitrary rank (needed to form gather groups without communication)
-void rank_level_table(int rank, std::vector<Level> &T) {
-  const int npx0 = S.npx, npy0 = S.npy, pi = rank % npx0, pj = rank / npx0;
+void rank_level_table(int rank, std::vector<Level> &T, int npx0, int npy0, int nsmall) {
+  const int pi = rank % npx0, pj = rank / npx0;
   int nx = T[0].nx, ny = T[0].ny, nz = T[0].nz, npx = npx0, npy = npy0, incx = 1, incy = 1;
   T[0].npx = npx; T[0].npy = npy; T[0].incx = 1; T[0].incy = 1; T[0].gather = 0; T[0].ngx = 1; T[0].ngy = 1; T[0].key = 0; T[0].color = 0;
   for (int l = 1; l < (int)T.size(); l++) {  // define_grid_dims :503-577
     Level &L = T[l];
     if (nz == 1) { nx /= 2; ny /= 2; } else { nx /= 2; ny /= 2; nz /= 2; }
     L.gather = 0; L.ngx = 1; L.ngy = 1; L.key = 0; L.color = 0;
-    if (((nx < ny ? nx : ny) < S.par.nsmall) && (npx * npy > 1)) {
+    if (((nx < ny ? nx : ny) < nsmall) && (npx * npy > 1)) {
       L.gather = 1;
       if (npx > 1) { npx /= 2; nx *= 2; L.ngx = 2; }
       if (npy > 1) { npy /= 2; ny *= 2; L.ngy = 2; }
@@ -592,7 +592,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (S.nlevs < 1) return fail("grid %dx%dx%d too small for a multigrid hierarchy", nx * npx, ny * npy, nz);
   S.lev.assign(S.nlevs, Level());
   S.lev[0].nx = nx; S.lev[0].ny = ny; S.lev[0].nz = nz;
-  rank_level_table(rank, S.lev);
+  rank_level_table(rank, S.lev, npx, npy, S.par.nsmall);
   for (int l = 0; l < S.nlevs; l++) {
     const Level &L = S.lev[l];
     if ((L.nx & 1) || (L.ny & 1) || L.nz < 2) return fail("level %d has local size %dx%dx%d: odd sizes are not supported (assumptions:1-2)", l + 1, L.nx, L.ny, L.nz);
@@ -605,7 +605,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int r = 0; r < S.nranks; r++) {
       std::vector<Level> T(S.nlevs);
       T[0].nx = nx; T[0].ny = ny; T[0].nz = nz;
-      rank_level_table(r, T);
+      rank_level_table(r, T, npx, npy, S.par.nsmall);
       if (T[l].color == L.color) mem.push_back({T[l].key, r});
     }
     std::sort(mem.begin(), mem.end());
@@ -744,6 +744,21 @@ int mgx_fill_halo(int lev, int field) {
   CHK(fill_halo_js(L, a));
   HIPCHK(hipStreamSynchronize(S.stream));
   return 0;
+}
+
+int mgx_level_table(int nx, int ny, int nz, int npx, int npy, int rank, int nsmall, int maxlev, int *out) {
+  if (nx < 2 || ny < 2 || nz < 2 || npx < 1 || npy < 1 || rank < 0 || rank >= npx * npy) return -1;
+  const int nl = find_grid_levels(npx, npy, nx, ny, nz);
+  if (nl < 1 || nl > maxlev) return -1;
+  std::vector<Level> T(nl);
+  T[0].nx = nx; T[0].ny = ny; T[0].nz = nz;
+  rank_level_table(rank, T, npx, npy, nsmall);
+  for (int l = 0; l < nl; l++) {
+    const Level &L = T[l];
+    const int v[12] = {L.nx, L.ny, L.nz, L.npx, L.npy, L.incx, L.incy, L.gather, L.ngx, L.ngy, L.key, L.color};
+    memcpy(out + 20 * l, v, sizeof(v)); memcpy(out + 20 * l + 12, L.neighb, 8 * sizeof(int));
+  }
+  return nl;
 }
 
 int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }

@@ -178,6 +178,21 @@ def grid(lev):
     return _Level(lev)
 
 
+def level_table(nx, ny, nz, npx=1, npy=1, rank=0, nsmall=8):
+    """Level hierarchy of `rank` (mg_grids.f90:468-738) as a list of dicts; pure host logic, no GPU needed."""
+    out = (C.c_int * (20 * 32))()
+    nl = lib().mgx_level_table(nx, ny, nz, npx, npy, rank, nsmall, 32, out)
+    if nl < 0:
+        raise MgxError("level_table: invalid arguments")
+    keys = ["nx", "ny", "nz", "npx", "npy", "incx", "incy", "gather", "ngx", "ngy", "key", "color"]
+    res = []
+    for l in range(nl):
+        d = dict(zip(keys, list(out[20 * l:20 * l + 12])))
+        d["neighb"] = list(out[20 * l + 12:20 * l + 20])
+        res.append(d)
+    return res
+
+
 # ---- measurement helpers (bench.py) -------------------------------------------------------------
 def time_relax(lev, reps):
     ms = C.c_float()

@@ -1,0 +1,137 @@
+"""Multi-GPU plumbing: the reference's MPI layer (src/mg_mpi_exchange.f90, src/mg_gather.f90) re-expressed as three
+callbacks that libmgx.so invokes with DEVICE pointers (include/mgx.h: mgx_set_comm).  One process per GPU;
+transport is torch.distributed -- backend "nccl" is RCCL over xGMI on ROCm.
+
+  exchange  <- fill_halo_*: 8-neighbour non-blocking send/recv  (mg_mpi_exchange.f90:504-718)
+               one batched group of isend/irecv per halo fill (ncclGroupStart/End underneath): on the fully
+               connected xGMI fabric every neighbour is one hop, all edges of a fill travel concurrently.
+  allreduce <- global_sum: 1 double                             (mg_mpi_exchange.f90:1555-1571)
+  allgather <- gather_3D on the 2x2 / 2x1 colour groups         (mg_gather.f90:126, mg_grids.f90:702-718)
+               done with point-to-point messages inside the group (<= 4 members): no sub-communicator needed.
+
+The data path never touches the host with the nccl backend.  With the gloo backend (CPU tests, and several ranks
+sharing one GPU on a development box) buffers are staged through host memory; `device="cpu"` lets the same code
+run on plain host pointers so the transport logic is testable without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import ALLGATHER_FN, ALLREDUCE_FN, EXCHANGE_FN
+
+
+class _DevPtr:
+    """Zero-copy torch view of `count` doubles at a raw device pointer (CUDA array interface)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class Comm:
+    def __init__(self, device="cuda", group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.device = device
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.staged = self.backend != "nccl"  # gloo moves host memory only
+        self._cache = {}
+        self.n_exchange = self.n_allreduce = self.n_allgather = 0
+        self._ex = EXCHANGE_FN(self._exchange)
+        self._ar = ALLREDUCE_FN(self._allreduce)
+        self._ag = ALLGATHER_FN(self._allgather)
+        self.last_error = None
+
+    # -- pointer -> tensor ---------------------------------------------------------------------
+    def _t(self, ptr, count):
+        key = (int(ptr), int(count))
+        t = self._cache.get(key)
+        if t is None:
+            if self.device == "cuda":
+                t = torch.as_tensor(_DevPtr(ptr, count), device="cuda")
+            else:
+                a = np.ctypeslib.as_array(C.cast(C.c_void_p(int(ptr)), C.POINTER(C.c_double)), shape=(int(count),))
+                t = torch.from_numpy(a)
+            self._cache[key] = t
+        return t
+
+    def _p2p(self, sends, recvs):
+        """sends/recvs: lists of (tensor, peer).  One batched group; returns when the data is usable in stream order."""
+        if not sends and not recvs:
+            return
+        if self.staged:
+            hs = [(t.detach().to("cpu", copy=True).contiguous(), p) for t, p in sends]
+            hr = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in recvs]
+            ops = [dist.P2POp(dist.irecv, t, p, self.group) for t, p in hr] + [dist.P2POp(dist.isend, t, p, self.group) for t, p in hs]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for (dst, _), (src, _) in zip(recvs, hr):
+                dst.copy_(src)
+        else:
+            ops = [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs] + [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()  # nccl: orders the current stream after the transfer, does not block the host
+
+    # -- callbacks (C ABI) ------------------------------------------------------------------------
+    def _exchange(self, ctx, n, peer, sendbuf, recvbuf, count):
+        try:
+            self.n_exchange += 1
+            sends = [(self._t(sendbuf[q], count[q]), int(peer[q])) for q in range(n)]
+            recvs = [(self._t(recvbuf[q], count[q]), int(peer[q])) for q in range(n)]
+            self._p2p(sends, recvs)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            self.last_error = e
+            return 1
+
+    def _allreduce(self, ctx, buf, n):
+        try:
+            self.n_allreduce += 1
+            t = self._t(buf, n)
+            if self.staged and self.device == "cuda":
+                h = t.to("cpu", copy=True)
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
+            return 0
+        except Exception as e:
+            self.last_error = e
+            return 1
+
+    def _allgather(self, ctx, group, ng, sendbuf, recvbuf, count):
+        try:
+            self.n_allgather += 1
+            members = [int(group[q]) for q in range(ng)]
+            me = members.index(self.rank)
+            src = self._t(sendbuf, count)
+            out = self._t(recvbuf, count * ng)
+            out[me * count:(me + 1) * count].copy_(src)
+            sends = [(src, m) for q, m in enumerate(members) if q != me]
+            recvs = [(out[q * count:(q + 1) * count], m) for q, m in enumerate(members) if q != me]
+            self._p2p(sends, recvs)
+            return 0
+        except Exception as e:
+            self.last_error = e
+            return 1
+
+    # -- wiring -------------------------------------------------------------------------------------
+    def callbacks(self):
+        return self._ex, self._ar, self._ag
+
+    def install(self):
+        """Hand the callbacks to libmgx.so and make it launch on torch's current stream, so that kernels,
+        packs/unpacks and the RCCL transfers are ordered on one stream."""
+        from ._lib import check, lib
+        check(lib().mgx_set_comm(self._ex, self._ar, self._ag, None))
+        if self.device == "cuda":
+            check(lib().mgx_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def process_grid(world):
+    """npx x npy used by bench.py for 1/2/4/8 GPUs (the reference's power-of-two cartesian grid, assumptions:1-6)."""
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2), 16: (4, 4)}[world]

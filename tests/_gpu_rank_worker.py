@@ -1,0 +1,61 @@
+"""One rank of a multi-rank GPU solve (tests/test_gpu_multirank.py).  All ranks share cuda:0 of the one-GPU box and
+talk over gloo with host staging (RCCL refuses several ranks on one device); everything else -- kernels, packs,
+neighbour tables, gather/split, callbacks -- is the code path the 8-GPU runs use."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, npx, npy, port, nx, ny, nz, nsmall = (int(a) for a in sys.argv[1:10])
+    method = sys.argv[10]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mgroms_amd as mg
+    from mgroms_amd import nhydro
+    from mgroms_amd.parallel import Comm
+    from oracle.mgoracle import make_seamount, seamount_geometry
+
+    nhydro.set_verbose(0)
+    comm = Comm(device="cuda")
+    par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall)
+    mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
+    dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
+    mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+    u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
+    nhydro.compute_rhs(u, v, w)
+    n, hist = mg.solve_p(1e-9, 30)
+
+    o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall)
+    o.compute_rhs()
+    no, ho, _ = o.solve_p(1e-9, 30)
+    assert mg.nlevs() == o.nlevs
+    gathered = [l for l in range(1, o.nlevs + 1) if o.level_info(l, rank)["gather"]]
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        for name in ("h", "zr", "cA"):
+            assert np.array_equal(g.get(name), o.field(name, lev, rank)), (rank, lev, name)
+    assert np.array_equal(mg.grid(1).b, o.field("b", 1, rank))
+    assert n == no, (n, no)
+    if method == "FC":  # order independent: every rank's block is bit-identical to the emulated-MPI oracle
+        assert np.array_equal(mg.grid(1).p, o.field("p", 1, rank)), rank
+        assert np.all(np.abs(hist - ho) <= 1e-13 + 1e-12 * np.abs(ho)), (hist, ho)
+    else:
+        assert np.all(np.abs(hist - ho) <= 1e-4 * np.abs(ho))
+    c = nhydro.counters()
+    assert c["exchanges"] > 0 and c["allreduces"] > 0
+    mg.nhydro_clean()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok nite={n} gathered_levels={gathered} exchanges={c['exchanges']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU tests of the product's host logic: library loads and exports every symbol of include/mgx.h, the level /
+neighbour / gather tables equal the oracle's (mg_grids.f90:468-738), the namelist parser, loud failure without a GPU."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import mgroms_amd
+    return mgroms_amd
+
+
+def test_every_declared_symbol_is_exported(built):
+    from mgroms_amd._lib import lib, SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    declared = set(re.findall(r"\b(mgx_[a-z_0-9]+)\s*\(", hdr)) - {"mgx_set_comm"} | {"mgx_set_comm"}
+    declared = {d for d in declared if not d.endswith("_fn")}
+    assert declared == set(SYMBOLS), declared ^ set(SYMBOLS)
+    L = lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+@pytest.mark.parametrize("cfg", [(64, 64, 16, 1, 1, 8), (32, 32, 16, 2, 2, 8), (512, 512, 64, 1, 1, 8), (64, 32, 32, 4, 2, 8),
+                                 (512, 512, 64, 2, 2, 8), (512, 1024, 128, 4, 2, 16), (128, 128, 64, 4, 2, 64), (16, 16, 8, 2, 1, 8),
+                                 (16, 16, 8, 1, 2, 8), (32, 64, 8, 4, 4, 16)])
+def test_level_tables_match_oracle(built, cfg):
+    from mgroms_amd import nhydro
+    from oracle.mgoracle import Oracle
+    nx, ny, nz, npx, npy, nsmall = cfg
+    small = nx * ny * nz * npx * npy <= 2 ** 22  # the oracle allocates every rank: only build it for small worlds
+    if not small:
+        t = nhydro.level_table(nx, ny, nz, npx, npy, 0, nsmall)
+        assert t[0]["nx"] == nx and all(d["nx"] % 2 == 0 for d in t)
+        return
+    o = Oracle(nx, ny, nz, npx, npy, nsmall=nsmall)
+    for rank in range(npx * npy):
+        t = nhydro.level_table(nx, ny, nz, npx, npy, rank, nsmall)
+        assert len(t) == o.nlevs
+        for lev, d in enumerate(t, start=1):
+            li = o.level_info(lev, rank)
+            for k in ("nx", "ny", "nz", "npx", "npy", "incx", "incy", "gather", "ngx", "ngy", "neighb"):
+                assert d[k] == li[k], (rank, lev, k)
+            if d["gather"]:
+                assert (d["key"], d["color"]) == (li["key"], li["color"])
+
+
+def test_baseline_config_levels(built):
+    from mgroms_amd import nhydro
+    # 512x512x64 -> 6 levels down to 16x16x2; 2048x2048x128 on 4x2 -> 7 levels, no gather at nsmall=8
+    t = nhydro.level_table(512, 512, 64)
+    assert len(t) == 6 and (t[-1]["nx"], t[-1]["nz"]) == (16, 2)
+    t = nhydro.level_table(512, 1024, 128, 4, 2, 0)
+    assert len(t) == 7 and not any(d["gather"] for d in t)
+    t = nhydro.level_table(512, 1024, 128, 4, 2, 0, nsmall=16)
+    assert any(d["gather"] for d in t)
+
+
+def test_namelist_parser(built, tmp_path):
+    from mgroms_amd import nhydro
+    from mgroms_amd._lib import MgxError
+    f = tmp_path / "nh_namelist"
+    f.write_text("!- comment\n&nhparam\n  solver_prec = 1.d-12, !- x\n  solver_maxiter = 7,\n  nsmall=16\n  relax_method = 'FC',\n"
+                 "  cmatrix='simple', interp_type = 'nearest', netcdf_output = .true., bmask = .false.,\n/\n")
+    p = nhydro.read_nhnamelist(str(f))
+    assert (p.solver_prec, p.solver_maxiter, p.nsmall, p.relax_method, p.cmatrix, p.interp_type, p.netcdf_output, p.bmask) == \
+        (1e-12, 7, 16, b"FC", b"simple", b"nearest", 1, 0)
+    d = nhydro.read_nhnamelist(str(tmp_path / "missing"))  # absent file: defaults (mg_namelist.f90:75-86)
+    assert (d.solver_prec, d.solver_maxiter, d.ns_coarsest, d.ns_pre, d.ns_post, d.relax_method) == (1e-6, 50, 40, 3, 2, b"RB")
+    g = tmp_path / "stale"
+    g.write_text("&nhparam\n nhalo = 1,\n/\n")  # the stale example in examples/namelist would abort a Fortran read too
+    with pytest.raises(MgxError):
+        nhydro.read_nhnamelist(str(g))
+    h = tmp_path / "lin"
+    h.write_text("&nhparam\n interp_type='linear', restrict_type='linear'\n/\n")
+    with pytest.raises(MgxError):
+        nhydro.read_nhnamelist(str(h))
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mgroms_amd import nhydro
+    from mgroms_amd._lib import MgxError
+    with pytest.raises(MgxError, match="no HIP device"):
+        nhydro.nhydro_init(16, 16, 8)
+    with pytest.raises(MgxError):
+        nhydro.relax(1, 1)
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "mgroms_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, fn)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", ""), fn
