@@ -26,6 +26,7 @@ struct ModelView { double *u, *v, *w, *rmask; };
 
 extern "C" {
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
+int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int);
@@ -83,6 +84,7 @@ struct State {
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
   std::vector<void *> allocs;
   int verbose = 1;
+  int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
   std::string err;
 };
@@ -292,6 +294,7 @@ int relax(int lev, int nsweeps) {
   if (S.method == M_GS)
     return fail("relax_method='GS' is a sequential lexicographic sweep (mg_relax.f90:131-144); this build runs the parallel orderings 'RB' and 'FC' only");
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
+  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph)) { S.n_launch++; return 0; }
   for (int it = 1; it <= nsweeps; it++) {
     if (S.method == M_RB) {
       for (int rb = 1; rb <= 2; rb++) {
@@ -660,6 +663,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
   CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   HIPCHK(hipStreamSynchronize(S.stream));
+  S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"

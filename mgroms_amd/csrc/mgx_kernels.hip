@@ -107,12 +107,7 @@ __global__ __launch_bounds__(256) void k_relax_colour(LevView L, int i0, int ist
 // Arithmetic and its order are identical to k_relax_colour (bit-identical results).
 // ------------------------------------------------------------------------------------------------
 template <int NZ, bool REAL, bool SNAP, int D>
-__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
-  const int jh = blockIdx.x * WAVE + threadIdx.x;
-  const int ipl = blockIdx.y;
-  if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
-  const int i = i0 + istep * ipl;
-  const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+__device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, const int jh, const int jodd, const Sides ph) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
   else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
@@ -215,6 +210,46 @@ __global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep
 #undef NB_LOAD
 #undef OW_LOAD
 #undef NB_USE
+}
+
+template <int NZ, bool REAL, bool SNAP, int D>
+__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int ipl = blockIdx.y;
+  if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
+  const int i = i0 + istep * ipl;
+  // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
+  const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
+}
+
+// Whole relax(lev, nsweeps) of a SMALL level (<= 1024 columns per colour, no neighbours) in ONE launch of ONE
+// workgroup: colours are separated by __syncthreads() instead of kernel boundaries.  The coarsest-level solve of
+// the reference (40 sweeps, mg_solvers.f90:117,144) is 160 colour passes of a 16x16x2 grid: launch-bound as
+// separate kernels, ~1 us per pass here.  method: 1 = RB, 2 = FC.
+template <int NZ, bool REAL>
+__global__ __launch_bounds__(256) void k_relax_small(LevView L, int nsweeps, int method, Sides ph) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int nyh = L.ny >> 1;
+  for (int it = 0; it < nsweeps; it++) {
+    const int ncolour = method == 2 ? 4 : 2;
+    for (int cidx = 0; cidx < ncolour; cidx++) {
+      if (method == 1 && REAL) {  // snapshot of p(k=1) for the same-colour diagonals of red-black
+        for (int t = tid; t < (L.nx + 2) * L.RS; t += nth) L.p1[t] = L.p[(long long)(t / L.RS) * L.plane + (t % L.RS)];
+        __syncthreads();
+      }
+      const int ncol = method == 2 ? (L.nx >> 1) * nyh : L.nx * nyh;
+      for (int t = tid; t < ncol; t += nth) {
+        const int ipl = t / nyh, jh = t - ipl * nyh;
+        int i, jodd;
+        if (method == 2) { i = 1 + (cidx >> 1) + 2 * ipl; jodd = (cidx & 1) == 0; }
+        else { i = 1 + ipl; jodd = ((i + cidx + 1) & 1) == 0; }
+        if (method == 1) relax_col_nz<NZ, REAL, REAL, 1>(L, i, jh, jodd, ph);
+        else relax_col_nz<NZ, REAL, false, 1>(L, i, jh, jodd, ph);
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // snapshot of p(k=1,:,:) for the parallel red-black pass
@@ -545,6 +580,19 @@ static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep,
 }
 
 extern "C" {
+
+// one-launch relax of a small level; returns 0 if the level does not qualify
+int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph) {
+  const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
+  // one CU streams ~25-50 GB/s: worth it only while the level is launch-bound, not bandwidth-bound (measured:
+  // 16x16x2 and 32x32x4 win, 64x64x8 loses 2x against separate launches over 256 CUs)
+  if (ncol > 256 || L->nz > 8 || !(ph.S && ph.E && ph.N && ph.W)) return 0;
+  const int nth = ncol <= 64 ? 64 : 256;
+#define SMALL_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_small<NZV, true>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); \
+                                  else hipLaunchKernelGGL((k_relax_small<NZV, false>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); return 1;
+  switch (L->nz) { SMALL_CASE(2) SMALL_CASE(4) SMALL_CASE(8) default: return 0; }
+#undef SMALL_CASE
+}
 
 // returns 1 when the launched kernel also wrote the physical-boundary mirrors of p (no k_halo_phys needed)
 int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {

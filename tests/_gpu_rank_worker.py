@@ -25,17 +25,20 @@ def main():
 
     nhydro.set_verbose(0)
     comm = Comm(device="cuda")
-    par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall)
+    par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6)
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
     mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
     u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
     nhydro.compute_rhs(u, v, w)
-    n, hist = mg.solve_p(1e-9, 30)
+    import time
+    t0 = time.time()
+    n, hist = mg.solve_p(1e-9, 3)
+    t_solve = time.time() - t0
 
-    o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall)
+    o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6)
     o.compute_rhs()
-    no, ho, _ = o.solve_p(1e-9, 30)
+    no, ho, _ = o.solve_p(1e-9, 3)
     assert mg.nlevs() == o.nlevs
     gathered = [l for l in range(1, o.nlevs + 1) if o.level_info(l, rank)["gather"]]
     for lev in range(1, o.nlevs + 1):
@@ -54,7 +57,7 @@ def main():
     mg.nhydro_clean()
     dist.barrier()
     dist.destroy_process_group()
-    print(f"rank {rank} ok nite={n} gathered_levels={gathered} exchanges={c['exchanges']}")
+    print(f"rank {rank} ok nite={n} gathered_levels={gathered} exchanges={c['exchanges']} solve_s={t_solve:.1f}")
 
 
 if __name__ == "__main__":

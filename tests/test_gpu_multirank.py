@@ -25,7 +25,7 @@ def _free_port():
     (1, 2, 16, 32, 8, 8, "FC"),     # 1x2: N/S exchange, ragged block
     (2, 2, 32, 32, 16, 8, "FC"),    # BASELINE 64x64x16 on 2x2: 8 neighbours + corners, 2x2 gather at level 4
     (2, 2, 32, 32, 16, 32, "FC"),   # nsmall=32: gathered from level 2 on (every coarse level runs redundantly)
-    (2, 2, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
+    (2, 1, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     world, port = npx * npy, _free_port()
@@ -35,7 +35,7 @@ def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=150)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
