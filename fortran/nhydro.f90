@@ -1,0 +1,103 @@
+!> Drop-in replacement of the reference's model-facing module (src/nhydro.f90): same module name, same five
+!> procedures with the same argument lists, bodies forwarding through ISO_C_BINDING to libmgx.so (include/mgx.h),
+!> whose operators are HIP kernels on the MI355X.  An ocean model (or the reference's own mg_testseamount driver)
+!> that does `use nhydro` links against this object + libmgx.so instead of the reference's solver modules.
+!>
+!> Differences a caller can observe: none in the interface.  The namelist ./nh_namelist is read by the library
+!> (same members, mg_namelist.f90:37-50); rank 0 prints the same parameter block / level table / "ite = " lines.
+!> Multi-rank runs need the three communication hooks of mgx_set_comm (INTEGRATION.md); this shim covers the
+!> single-process case, nhydro_init(nx,ny,nz,1,1).
+module nhydro
+  use iso_c_binding
+  implicit none
+  integer(kind=4), parameter :: rp = 8, ip = 4
+  integer(kind=4) :: nhydro_rank = 0   !< set before nhydro_init when the caller has an MPI rank
+
+  interface
+     integer(c_int) function mgx_init(nx, ny, nz, npx, npy, rank, par) bind(C, name='mgx_init')
+       import :: c_int, c_ptr
+       integer(c_int), value :: nx, ny, nz, npx, npy, rank
+       type(c_ptr), value :: par
+     end function mgx_init
+     integer(c_int) function mgx_matrices(dx, dy, zeta, h, rmask, hc, theta_b, theta_s) bind(C, name='mgx_matrices')
+       import :: c_int, c_double, c_ptr
+       real(c_double), intent(in) :: dx(*), dy(*), zeta(*), h(*)
+       type(c_ptr), value :: rmask
+       real(c_double), value :: hc, theta_b, theta_s
+     end function mgx_matrices
+     integer(c_int) function mgx_solve(u, v, w, rmask) bind(C, name='mgx_solve')
+       import :: c_int, c_double, c_ptr
+       real(c_double), intent(inout) :: u(*), v(*), w(*)
+       type(c_ptr), value :: rmask
+     end function mgx_solve
+     integer(c_int) function mgx_check_nondivergence(u, v, w, rmask) bind(C, name='mgx_check_nondivergence')
+       import :: c_int, c_double, c_ptr
+       real(c_double), intent(inout) :: u(*), v(*), w(*)
+       type(c_ptr), value :: rmask
+     end function mgx_check_nondivergence
+     subroutine mgx_clean() bind(C, name='mgx_clean')
+     end subroutine mgx_clean
+     integer(c_int) function mgx_get_field(lev, field, host) bind(C, name='mgx_get_field')
+       import :: c_int, c_double
+       integer(c_int), value :: lev, field
+       real(c_double), intent(out) :: host(*)
+     end function mgx_get_field
+     type(c_ptr) function mgx_last_error() bind(C, name='mgx_last_error')
+       import :: c_ptr
+     end function mgx_last_error
+  end interface
+
+contains
+
+  subroutine mgx_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    if (rc /= 0) then
+       write(*,*) 'Error in ', where, ' (libmgx), see stderr'
+       stop -1   ! the reference's error behaviour (mg_grids.f90:530,657)
+    endif
+  end subroutine mgx_check
+
+  !--------------------------------------------------------------  (nhydro.f90:18-33)
+  subroutine nhydro_init(nx, ny, nz, npxg, npyg)
+    integer(kind=ip), intent(in) :: nx, ny, nz
+    integer(kind=ip), intent(in) :: npxg, npyg
+    call mgx_check(mgx_init(nx, ny, nz, npxg, npyg, nhydro_rank, c_null_ptr), 'nhydro_init')
+  end subroutine nhydro_init
+
+  !--------------------------------------------------------------  (nhydro.f90:36-50)
+  subroutine nhydro_matrices(dx, dy, zeta, h, rmask, hc, theta_b, theta_s)
+    real(kind=rp), dimension(:,:)         , intent(in) :: dx, dy, zeta, h
+    real(kind=rp), dimension(:,:), pointer, intent(in) :: rmask
+    real(kind=rp)                         , intent(in) :: hc, theta_b, theta_s
+    real(kind=rp), dimension(:,:), allocatable :: a, b, c, d   ! contiguous copies of the assumed-shape arguments
+    allocate(a, source=dx); allocate(b, source=dy); allocate(c, source=zeta); allocate(d, source=h)
+    call mgx_check(mgx_matrices(a, b, c, d, c_null_ptr, hc, theta_b, theta_s), 'nhydro_matrices')
+  end subroutine nhydro_matrices
+
+  !--------------------------------------------------------------  (nhydro.f90:53-102)
+  subroutine nhydro_solve(nx, ny, nz, rmaska, ua, va, wa)
+    integer(kind=ip), intent(in) :: nx, ny, nz
+    real(kind=rp), dimension(0:nx+1,0:ny+1)     , target, intent(inout) :: rmaska
+    real(kind=rp), dimension(1:nx+1,0:ny+1,1:nz), target, intent(inout) :: ua
+    real(kind=rp), dimension(0:nx+1,1:ny+1,1:nz), target, intent(inout) :: va
+    real(kind=rp), dimension(0:nx+1,0:ny+1,0:nz), target, intent(inout) :: wa
+    call mgx_check(mgx_solve(ua, va, wa, c_null_ptr), 'nhydro_solve')
+  end subroutine nhydro_solve
+
+  !--------------------------------------------------------------  (nhydro.f90:105-134)
+  subroutine nhydro_check_nondivergence(nx, ny, nz, rmaska, ua, va, wa)
+    integer(kind=ip), intent(in) :: nx, ny, nz
+    real(kind=rp), dimension(0:nx+1,0:ny+1)     , target, intent(inout) :: rmaska
+    real(kind=rp), dimension(1:nx+1,0:ny+1,1:nz), target, intent(inout) :: ua
+    real(kind=rp), dimension(0:nx+1,1:ny+1,1:nz), target, intent(inout) :: va
+    real(kind=rp), dimension(0:nx+1,0:ny+1,0:nz), target, intent(inout) :: wa
+    call mgx_check(mgx_check_nondivergence(ua, va, wa, c_null_ptr), 'nhydro_check_nondivergence')
+  end subroutine nhydro_check_nondivergence
+
+  !--------------------------------------------------------------  (nhydro.f90:137-141)
+  subroutine nhydro_clean()
+    call mgx_clean()
+  end subroutine nhydro_clean
+
+end module nhydro

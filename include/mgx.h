@@ -74,6 +74,7 @@ void mgx_clean(void);
 int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist);
 int mgx_fcycle(void);                     /* mg_solvers.f90:104-126 */
 int mgx_vcycle(int lev);                  /* mg_solvers.f90:129-151 */
+int mgx_vcycle2(int lev1, int lev2);      /* mg_solvers.f90:155-177 partial V-cycle down to lev2 */
 int mgx_relax(int lev, int nsweeps);      /* mg_relax.f90:16-47   */
 int mgx_residual(int lev, double *res);   /* mg_relax.f90:337-383: r = b - A p, halo fill of r, *res = global ||r||_2 */
 int mgx_fine2coarse(int lev);             /* mg_intergrids.f90:16-72  */

@@ -6,9 +6,9 @@ fallback: importing works anywhere, but every solver call needs the built librar
 """
 from . import nhydro  # noqa: F401
 from .nhydro import (nhydro_init, nhydro_matrices, nhydro_solve, nhydro_check_nondivergence, nhydro_clean,  # noqa: F401
-                     solve_p, Fcycle, Vcycle, relax, compute_residual, fine2coarse, coarse2fine, fill_halo,
+                     solve_p, Fcycle, Vcycle, Vcycle2, relax, compute_residual, fine2coarse, coarse2fine, fill_halo,
                      grid, nlevs, Params, read_nhnamelist)
 
 __all__ = ["nhydro", "nhydro_init", "nhydro_matrices", "nhydro_solve", "nhydro_check_nondivergence", "nhydro_clean",
-           "solve_p", "Fcycle", "Vcycle", "relax", "compute_residual", "fine2coarse", "coarse2fine", "fill_halo",
+           "solve_p", "Fcycle", "Vcycle", "Vcycle2", "relax", "compute_residual", "fine2coarse", "coarse2fine", "fill_halo",
            "grid", "nlevs", "Params", "read_nhnamelist"]

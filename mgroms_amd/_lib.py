@@ -36,6 +36,7 @@ _SIGS = {
     "mgx_solve_p": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_int), _DP, _DP]),
     "mgx_fcycle": (C.c_int, []),
     "mgx_vcycle": (C.c_int, [C.c_int]),
+    "mgx_vcycle2": (C.c_int, [C.c_int, C.c_int]),
     "mgx_relax": (C.c_int, [C.c_int, C.c_int]),
     "mgx_residual": (C.c_int, [C.c_int, _DP]),
     "mgx_fine2coarse": (C.c_int, [C.c_int]),

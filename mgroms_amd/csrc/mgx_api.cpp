@@ -374,6 +374,21 @@ int vcycle(int lev1) {
   return 0;
 }
 
+// mg_solvers.f90:155-177: partial V-cycle down to level lev2
+int vcycle2(int lev1, int lev2) {
+  for (int lev = lev1; lev <= lev2 - 1; lev++) {
+    CHK(relax(lev, S.par.ns_pre));
+    CHK(residual(lev, nullptr));
+    CHK(fine2coarse(lev));
+  }
+  CHK(relax(lev2, S.par.ns_coarsest));
+  for (int lev = lev2 - 1; lev >= lev1; lev--) {
+    CHK(coarse2fine(lev));
+    CHK(relax(lev, S.par.ns_post));
+  }
+  return 0;
+}
+
 // mg_solvers.f90:104-126
 int fcycle() {
   for (int lev = 1; lev <= S.nlevs - 1; lev++) {
@@ -736,6 +751,7 @@ int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist) {
 }
 int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
 int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_vcycle2(int lev1, int lev2) { NEED_LEV(lev1); NEED_LEV(lev2); if (lev2 < lev1) return fail("Vcycle2: lev2 < lev1"); CHK(vcycle2(lev1, lev2)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
 int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
 int mgx_residual(int lev, double *res) { NEED_LEV(lev); double r; CHK(residual(lev, &r)); if (res) *res = r; return 0; }
 int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }

@@ -112,6 +112,10 @@ def Vcycle(lev=1):
     check(lib().mgx_vcycle(lev))
 
 
+def Vcycle2(lev1, lev2):
+    check(lib().mgx_vcycle2(lev1, lev2))
+
+
 def relax(lev, nsweeps):
     check(lib().mgx_relax(lev, nsweeps))
 
