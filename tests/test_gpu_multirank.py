@@ -25,6 +25,7 @@ def _free_port():
     (1, 2, 16, 32, 8, 8, "FC"),     # 1x2: N/S exchange, ragged block
     (2, 2, 32, 32, 16, 8, "FC"),    # BASELINE 64x64x16 on 2x2: 8 neighbours + corners, 2x2 gather at level 4
     (2, 2, 32, 32, 16, 32, "FC"),   # nsmall=32: gathered from level 2 on (every coarse level runs redundantly)
+    (4, 1, 16, 32, 8, 16, "FC"),    # 4x1 with nsmall=16: two consecutive gathers (4 -> 2 -> 1 ranks), as bench.py uses for N>1
     (2, 1, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
