@@ -64,6 +64,9 @@ int mgx_matrices(const double *dx, const double *dy, const double *zeta, const d
                  double hc, double theta_b, double theta_s);
 /* nhydro_solve(nx,ny,nz,rmask,u,v,w) (nhydro.f90:53-102): compute_rhs, solve_p, correct_uvw; u,v,w updated in place */
 int mgx_solve(double *u, double *v, double *w, const double *rmask);
+/* nhydro_solve with the model state already on the GPU: u,v,w are DEVICE pointers (same (i,j,k) layout); no PCIe traffic.
+ * This is what a GPU-resident ocean model calls every time step. */
+int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *rmask);
 /* nhydro_check_nondivergence (nhydro.f90:105-134): recompute the divergence into grid(1)%b */
 int mgx_check_nondivergence(double *u, double *v, double *w, const double *rmask);
 /* nhydro_clean (nhydro.f90:137-141) */

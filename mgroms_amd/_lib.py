@@ -31,6 +31,7 @@ _SIGS = {
     "mgx_init": (C.c_int, [C.c_int] * 6 + [C.POINTER(Params)]),
     "mgx_matrices": (C.c_int, [_DP, _DP, _DP, _DP, _DP, C.c_double, C.c_double, C.c_double]),
     "mgx_solve": (C.c_int, [_DP, _DP, _DP, _DP]),
+    "mgx_solve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_check_nondivergence": (C.c_int, [_DP, _DP, _DP, _DP]),
     "mgx_clean": (None, []),
     "mgx_solve_p": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_int), _DP, _DP]),

@@ -27,6 +27,7 @@ struct ModelView { double *u, *v, *w, *rmask; };
 extern "C" {
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides);
+int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int);
@@ -291,8 +292,14 @@ int global_sum(const Level &L, double *out) {
 // mg_relax.f90:16-47 relax ; :151-190 RB ; :193-234 FC
 int relax(int lev, int nsweeps) {
   Level &L = S.lev[lev - 1];
-  if (S.method == M_GS)
-    return fail("relax_method='GS' is a sequential lexicographic sweep (mg_relax.f90:131-144); this build runs the parallel orderings 'RB' and 'FC' only");
+  if (S.method == M_GS) {  // exact lexicographic order by hyperplanes; halo fill once per sweep (mg_relax.f90:131-141)
+    for (int it = 1; it <= nsweeps; it++) {
+      if (!mgxk_relax_gs_sweep(S.stream, &L.v, S.real)) return fail("relax_method='GS': nz=%d has no register-resident kernel (nz must be a power of two <= 64)", L.nz);
+      S.n_launch += L.ny + 2 * L.nx - 2;
+      CHK(fill_halo_js(L, L.v.p));
+    }
+    return 0;
+  }
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph)) { S.n_launch++; return 0; }
   for (int it = 1; it <= nsweeps; it++) {
@@ -737,6 +744,26 @@ int mgx_solve(double *u, double *v, double *w, const double *rmask) {
   HIPCHK(hipMemcpyAsync(w, S.d_w, nw * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   HIPCHK(hipStreamSynchronize(S.stream));
   return 0;
+}
+
+// Device-resident variant of nhydro_solve: u,v,w are DEVICE pointers in the model's (i,j,k) layout
+// (e.g. torch tensors); nothing crosses PCIe.  The library's own staging copies are bypassed.
+int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *rmask) {
+  NEED_INIT();
+  (void)rmask;
+  if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve_device");
+  double *su = S.d_u, *sv = S.d_v, *sw = S.d_w;
+  S.d_u = u_dev; S.d_v = v_dev; S.d_w = w_dev;
+  int rc = compute_rhs_dev();
+  if (!rc) rc = solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr);
+  if (!rc) {
+    Level &L = S.lev[0];
+    ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+    mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
+    if (hipStreamSynchronize(S.stream) != hipSuccess) rc = fail("stream synchronize failed");
+  }
+  S.d_u = su; S.d_v = sv; S.d_w = sw;
+  return rc;
 }
 
 int mgx_check_nondivergence(double *u, double *v, double *w, const double *rmask) {

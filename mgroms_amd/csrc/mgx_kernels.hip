@@ -116,7 +116,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
   const double *__restrict__ b = L.b;
   const double *__restrict__ a2 = L.cA[1], *__restrict__ a3 = L.cA[2], *__restrict__ a4 = L.cA[3],
                *__restrict__ a5 = L.cA[4], *__restrict__ a6 = L.cA[5], *__restrict__ a7 = L.cA[6],
-               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ gam = L.gam;
+               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
 
   constexpr int RN = D + 1;  // raw neighbour rows in flight
@@ -137,7 +137,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
     o_b[s_] = b[ko_]; o_a2[s_] = a2[ko_]; o_a3[s_] = a3[ko_]; o_a4[s_] = a4[ko_]; o_a5[s_] = a5[ko_]; \
-    o_a6[s_] = a6[ko_]; o_a7[s_] = a7[ko_]; o_a8[s_] = a8[ko_]; o_bet[s_] = bet[ko_]; g[(q)-1] = gam[ko_]; \
+    o_a6[s_] = a6[ko_]; o_a7[s_] = a7[ko_]; o_a8[s_] = a8[ko_]; o_bet[s_] = bet[ko_]; \
   }
   // products of a raw neighbour row (computed when the row is first needed)
 #define NB_USE(q, PJM, PIM, M3, M4, M5, N6, N7, N8)                              \
@@ -163,7 +163,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
   double m3_m = 0, m3_0, m4_0, m5_p, n6_m = 0, n6_0, n7_0, n8_p, m3_p, m4_p, n6_p, n7_p, dum5, dum8;
   NB_USE(1, pjm_0, pim_0, m3_0, m4_0, dum5, n6_0, n7_0, dum8)
   (void)dum5; (void)dum8;
-  double xv = 0.0;
+  double xv = 0.0, betp = 0.0;
 #pragma unroll
   for (int k = 1; k <= NZ; k++) {
     // keep the pipeline full
@@ -172,6 +172,9 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
     if (k < NZ) { NB_USE(k + 1, pjm_p, pim_p, m3_p, m4_p, m5_p, n6_p, n7_p, n8_p) }
     const int s = k % RO;
     double rhs;
+    // gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325), from values already in registers: no gam stream from HBM
+    if (k > 1) g[k - 1] = o_a2[s] * betp;
+    betp = o_bet[s];
     if (k == 1) {
       rhs = o_b[s] - o_a3[s] * pjm_p - o_a4[s] * pjm_0 - m4_0 - m5_p - o_a6[s] * pim_p - o_a7[s] * pim_0 - n7_0 - n8_p;
       if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4;
@@ -221,6 +224,20 @@ __global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
   relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
+}
+
+// Lexicographic Gauss-Seidel (mg_relax.f90:116-148) on the device, EXACTLY: column (j,i) of the reference's
+// `do i; do j` sweep reads new values of (j-1,i), (j,i-1), (j+1,i-1), (j-1,i-1) and old values of the rest, so all
+// columns with equal t = j + 2 i are independent and hyperplanes t = 3 .. ny+2nx are processed in order (one
+// launch each).  Slow (launch-bound, ~ny+2nx launches per sweep) but bit-identical to the sequential loop.
+template <int NZ, bool REAL>
+__global__ __launch_bounds__(64, 1) void k_relax_gs_front(LevView L, int t) {
+  int ilo = (t - L.ny + 1) / 2; if (ilo < 1) ilo = 1;        // j = t - 2i <= ny
+  const int i = ilo + blockIdx.x * WAVE + threadIdx.x;
+  const int j = t - 2 * i;
+  if (i > L.nx || j < 1 || j > L.ny) return;
+  const Sides none = {0, 0, 0, 0};  // halo is refreshed once per sweep, after the loop (mg_relax.f90:141)
+  relax_col_nz<NZ, REAL, false, 1>(L, i, (j - 1) >> 1, j & 1, none);
 }
 
 // Whole relax(lev, nsweeps) of a SMALL level (<= 1024 columns per colour, no neighbours) in ONE launch of ONE
@@ -404,8 +421,9 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
 template <bool LINEAR>
 __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
-  const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-  if (j2 > C.ny || i2 > C.nx) return;
+  const int k2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int i2 = 1 + blockIdx.z;
+  if (j2 > C.ny || k2 > C.nz) return;
   const int i = 2 * i2 - 1;
   const int po = F.HO + (j2 - 1), pe = F.EO + j2;  // fine j (odd) and j+1 (even)
   const int c0 = jpos(C, j2), cm = jpos(C, j2 - 1), cp = jpos(C, j2 + 1);
@@ -414,40 +432,42 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
   double *__restrict__ rf = F.r;
   double *__restrict__ pf = F.p;
   const int nz = C.nz;
-#define XC(k2, JJ, QQ) xc[QQ + (long long)((k2)-1) * C.RS + JJ]
+#define XC(kk, JJ, QQ) xc[QQ + (long long)((kk)-1) * C.RS + JJ]
 #define PUT(k, OO, PP, val) { const long long t_ = OO + (long long)((k)-1) * F.RS + PP; const double v_ = (val); rf[t_] = v_; pf[t_] = pf[t_] + v_; }
   if (!LINEAR) {
-    for (int k2 = 1; k2 <= nz; k2++) {
-      const double v = XC(k2, c0, q0);
-      const int k = 2 * k2 - 1;
-      PUT(k, o0, po, v); PUT(k + 1, o0, po, v); PUT(k, o0, pe, v); PUT(k + 1, o0, pe, v);
-      PUT(k, o1, po, v); PUT(k + 1, o1, po, v); PUT(k, o1, pe, v); PUT(k + 1, o1, pe, v);
-    }
+    const double v = XC(k2, c0, q0);
+    const int k = 2 * k2 - 1;
+    PUT(k, o0, po, v); PUT(k + 1, o0, po, v); PUT(k, o0, pe, v); PUT(k + 1, o0, pe, v);
+    PUT(k, o1, po, v); PUT(k + 1, o1, po, v); PUT(k, o1, pe, v); PUT(k + 1, o1, pe, v);
     return;
   }
   const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
-  int k2 = 1;
-  PUT(1, o0, po, +a * XC(k2, c0, q0) + c * XC(k2, cm, qm) + b * XC(k2, cm, q0) + b * XC(k2, c0, qm));
-  PUT(1, o0, pe, +a * XC(k2, c0, q0) + c * XC(k2, cp, qm) + b * XC(k2, cp, q0) + b * XC(k2, c0, qm));
-  PUT(1, o1, po, +a * XC(k2, c0, q0) + c * XC(k2, cm, qp) + b * XC(k2, cm, q0) + b * XC(k2, c0, qp));
-  PUT(1, o1, pe, +a * XC(k2, c0, q0) + c * XC(k2, cp, qp) + b * XC(k2, cp, q0) + b * XC(k2, c0, qp));
-  for (int k = 2; k <= nz * 2 - 1; k++) {
-    k2 = (k + 1) / 2;
-    const int kp = k2 - ((k % 2) * 2 - 1);
-    PUT(k, o0, po, +d * XC(k2, c0, q0) + f * XC(k2, cm, qm) + e * XC(k2, cm, q0) + e * XC(k2, c0, qm)
-                   + e * XC(kp, c0, q0) + g * XC(kp, cm, qm) + f * XC(kp, cm, q0) + f * XC(kp, c0, qm));
-    PUT(k, o0, pe, +d * XC(k2, c0, q0) + f * XC(k2, cp, qm) + e * XC(k2, cp, q0) + e * XC(k2, c0, qm)
-                   + e * XC(kp, c0, q0) + g * XC(kp, cp, qm) + f * XC(kp, cp, q0) + f * XC(kp, c0, qm));
-    PUT(k, o1, po, +d * XC(k2, c0, q0) + f * XC(k2, cm, qp) + e * XC(k2, cm, q0) + e * XC(k2, c0, qp)
-                   + e * XC(kp, c0, q0) + g * XC(kp, cm, qp) + f * XC(kp, cm, q0) + f * XC(kp, c0, qp));
-    PUT(k, o1, pe, +d * XC(k2, c0, q0) + f * XC(k2, cp, qp) + e * XC(k2, cp, q0) + e * XC(k2, c0, qp)
-                   + e * XC(kp, c0, q0) + g * XC(kp, cp, qp) + f * XC(kp, cp, q0) + f * XC(kp, c0, qp));
+  // the 9 coarse values of level k2 around (j2,i2)
+  const double x00 = XC(k2, c0, q0), xmm = XC(k2, cm, qm), xm0 = XC(k2, cm, q0), x0m = XC(k2, c0, qm),
+               xpm = XC(k2, cp, qm), xp0 = XC(k2, cp, q0), xmp = XC(k2, cm, qp), x0p = XC(k2, c0, qp), xpp = XC(k2, cp, qp);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const int k = 2 * k2 - 1 + half;  // fine level
+    if (k == 1) {                      // bottom level: bilinear (mg_intergrids.f90:392-405)
+      PUT(1, o0, po, +a * x00 + c * xmm + b * xm0 + b * x0m);
+      PUT(1, o0, pe, +a * x00 + c * xpm + b * xp0 + b * x0m);
+      PUT(1, o1, po, +a * x00 + c * xmp + b * xm0 + b * x0p);
+      PUT(1, o1, pe, +a * x00 + c * xpp + b * xp0 + b * x0p);
+    } else if (k == 2 * nz) {          // top level: 1/2 bilinear (:434-446)
+      PUT(k, o0, po, 0.5 * (a * x00 + c * xmm + b * xm0 + b * x0m));
+      PUT(k, o0, pe, 0.5 * (a * x00 + c * xpm + b * xp0 + b * x0m));
+      PUT(k, o1, po, 0.5 * (a * x00 + c * xmp + b * xm0 + b * x0p));
+      PUT(k, o1, pe, 0.5 * (a * x00 + c * xpp + b * xp0 + b * x0p));
+    } else {                           // interior: tri-linear, kp = k2-1 for odd k, k2+1 for even k (:407-432)
+      const int kp = k2 - ((k % 2) * 2 - 1);
+      const double y00 = XC(kp, c0, q0), ymm = XC(kp, cm, qm), ym0 = XC(kp, cm, q0), y0m = XC(kp, c0, qm),
+                   ypm = XC(kp, cp, qm), yp0 = XC(kp, cp, q0), ymp = XC(kp, cm, qp), y0p = XC(kp, c0, qp), ypp = XC(kp, cp, qp);
+      PUT(k, o0, po, +d * x00 + f * xmm + e * xm0 + e * x0m + e * y00 + g * ymm + f * ym0 + f * y0m);
+      PUT(k, o0, pe, +d * x00 + f * xpm + e * xp0 + e * x0m + e * y00 + g * ypm + f * yp0 + f * y0m);
+      PUT(k, o1, po, +d * x00 + f * xmp + e * xm0 + e * x0p + e * y00 + g * ymp + f * ym0 + f * y0p);
+      PUT(k, o1, pe, +d * x00 + f * xpp + e * xp0 + e * x0p + e * y00 + g * ypp + f * yp0 + f * y0p);
+    }
   }
-  const int k = nz * 2;  // top level: k2 keeps its last value (mg_intergrids.f90:434)
-  PUT(k, o0, po, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cm, qm) + b * XC(k2, cm, q0) + b * XC(k2, c0, qm)));
-  PUT(k, o0, pe, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cp, qm) + b * XC(k2, cp, q0) + b * XC(k2, c0, qm)));
-  PUT(k, o1, po, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cm, qp) + b * XC(k2, cm, q0) + b * XC(k2, c0, qp)));
-  PUT(k, o1, pe, 0.5 * (a * XC(k2, c0, q0) + c * XC(k2, cp, qp) + b * XC(k2, cp, q0) + b * XC(k2, c0, qp)));
 #undef XC
 #undef PUT
 }
@@ -581,6 +601,21 @@ static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep,
 
 extern "C" {
 
+// one Gauss-Seidel sweep as ny+2nx-2 hyperplane launches; returns 0 when nz has no register-resident variant
+int mgxk_relax_gs_sweep(hipStream_t st, const LevView *L, int real) {
+  for (int t = 3; t <= L->ny + 2 * L->nx; t++) {
+    int ilo = (t - L->ny + 1) / 2; if (ilo < 1) ilo = 1;
+    int ihi = (t - 1) / 2; if (ihi > L->nx) ihi = L->nx;
+    if (ihi < ilo) continue;
+    dim3 grd((ihi - ilo + 1 + WAVE - 1) / WAVE), blk(WAVE);
+#define GS_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_gs_front<NZV, true>), grd, blk, 0, st, *L, t); \
+                               else hipLaunchKernelGGL((k_relax_gs_front<NZV, false>), grd, blk, 0, st, *L, t); break;
+    switch (L->nz) { GS_CASE(2) GS_CASE(4) GS_CASE(8) GS_CASE(16) GS_CASE(32) GS_CASE(64) default: return 0; }
+#undef GS_CASE
+  }
+  return 1;
+}
+
 // one-launch relax of a small level; returns 0 if the level does not qualify
 int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph) {
   const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
@@ -630,8 +665,10 @@ void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double
   hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst);
 }
 void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear) {
-  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, src);
-  else hipLaunchKernelGGL((k_coarse2fine<false>), col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, src);
+  const int by = C->nz >= 4 ? 4 : C->nz;
+  dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
+  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src);
+  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src);
 }
 void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
   const int n = L->nx + L->ny + 1;

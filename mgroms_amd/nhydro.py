@@ -79,6 +79,17 @@ def nhydro_solve(u, v, w, rmask=None):
     check(lib().mgx_solve(_dp(u), _dp(v), _dp(w), None))
 
 
+def nhydro_solve_device(u, v, w):
+    """nhydro_solve on torch CUDA tensors (float64, contiguous, shapes as nhydro_solve): no host round trip."""
+    nx, ny, nz = _state["dims"]
+    for a, sh, n in ((u, (nz, ny + 2, nx + 1), "u"), (v, (nz, ny + 1, nx + 2), "v"), (w, (nz + 1, ny + 2, nx + 2), "w")):
+        if not (a.is_cuda and a.is_contiguous() and tuple(a.shape) == sh and str(a.dtype) == "torch.float64"):
+            raise ValueError(f"{n}: need a contiguous float64 CUDA tensor of shape {sh}")
+    import torch
+    torch.cuda.current_stream().synchronize()
+    check(lib().mgx_solve_device(C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(w.data_ptr()), None))
+
+
 def nhydro_check_nondivergence(u, v, w, rmask=None):
     _uvw(u, v, w)
     check(lib().mgx_check_nondivergence(_dp(u), _dp(v), _dp(w), None))
