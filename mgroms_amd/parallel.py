@@ -40,6 +40,7 @@ class Comm:
         self.backend = dist.get_backend(group)
         self.staged = self.backend != "nccl"  # gloo moves host memory only
         self._cache = {}
+        self._ops = {}
         self.n_exchange = self.n_allreduce = self.n_allgather = 0
         self._ex = EXCHANGE_FN(self._exchange)
         self._ar = ALLREDUCE_FN(self._allreduce)
@@ -59,9 +60,18 @@ class Comm:
             self._cache[key] = t
         return t
 
-    def _p2p(self, sends, recvs):
-        """sends/recvs: lists of (tensor, peer).  One batched group; returns when the data is usable in stream order."""
+    def _p2p(self, sends, recvs, key=None):
+        """sends/recvs: lists of (tensor, peer).  One batched group; returns when the data is usable in stream order.
+        `key` identifies a recurring exchange (same buffers, peers, counts): its P2POp list is built once."""
         if not sends and not recvs:
+            return
+        if not self.staged and key is not None:
+            ops = self._ops.get(key)
+            if ops is None:
+                ops = [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs] + [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends]
+                self._ops[key] = ops
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
             return
         if self.staged:
             hs = [(t.detach().to("cpu", copy=True).contiguous(), p) for t, p in sends]
@@ -80,9 +90,13 @@ class Comm:
     def _exchange(self, ctx, n, peer, sendbuf, recvbuf, count):
         try:
             self.n_exchange += 1
+            key = tuple((int(peer[q]), int(sendbuf[q]), int(recvbuf[q]), int(count[q])) for q in range(n))
+            if not self.staged and key in self._ops:
+                self._p2p(True, True, key)
+                return 0
             sends = [(self._t(sendbuf[q], count[q]), int(peer[q])) for q in range(n)]
             recvs = [(self._t(recvbuf[q], count[q]), int(peer[q])) for q in range(n)]
-            self._p2p(sends, recvs)
+            self._p2p(sends, recvs, key)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             self.last_error = e

@@ -8,7 +8,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ncyc = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 # the last `1/ncyc` of the dispatches after set-up: find V-cycle boundaries = the level-1 residual kernel launches
-big = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_residual") and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100000]
+res = [(i, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_residual")]
+mx = max(d for _, d in res)
+big = [i for i, d in res if d > 0.7 * mx]  # the level-1 residual launches
 lo, hi = big[-2] + 0, big[-1]  # one full cycle between two level-1 residuals
 sel = rows[lo:hi]
 tot = collections.defaultdict(lambda: [0, 0])
