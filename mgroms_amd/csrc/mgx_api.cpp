@@ -46,6 +46,7 @@ void mgxs_rect(hipStream_t, double *, double *, const RectOp *);
 void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
 void mgxs_define_matrix(hipStream_t, const GeoView *, int);
 void mgxs_pivots(hipStream_t, const LevView *);
+void mgxs_slopes_js(hipStream_t, const GeoView *, const LevView *);
 void mgxs_rhs_uf(hipStream_t, const GeoView *, const ModelView *, double *);
 void mgxs_rhs_vf(hipStream_t, const GeoView *, const ModelView *, double *);
 void mgxs_rhs_wf(hipStream_t, const GeoView *, const ModelView *, double *);
@@ -67,6 +68,7 @@ struct Level {
   double *blk, *gbuf;  // all-gather send / receive (reference layout blocks incl. halo)
   int group[4], ngroup;
   size_t n3js;  // doubles in one JS array
+  double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
 };
 
 struct State {
@@ -85,6 +87,7 @@ struct State {
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
   std::vector<void *> allocs;
   int verbose = 1;
+  int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
   std::string err;
@@ -479,6 +482,9 @@ int define_matrices() {
     mgxs_define_matrix(S.stream, &L.g, l == 0); S.n_launch += 3;
     for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
+    L.v.zy = L.zy_store; L.v.zx = L.zx_store;
+    mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
+    if (S.no_mf) L.v.zy = L.v.zx = nullptr;
   }
   HIPCHK(hipStreamSynchronize(S.stream));
   S.have_matrix = true;
@@ -648,6 +654,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int s = 0; s < 8; s++) CHK(dmalloc(&L.v.cA[s], L.n3js));
     CHK(dmalloc(&L.v.bet, L.n3js)); CHK(dmalloc(&L.v.gam, L.n3js));
     CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS));
+    CHK(dmalloc(&L.zy_store, L.n3js)); CHK(dmalloc(&L.zx_store, L.n3js));
+    L.v.zy = L.v.zx = nullptr;
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
     CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));
@@ -686,6 +694,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   HIPCHK(hipStreamSynchronize(S.stream));
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
+  S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
@@ -864,6 +873,7 @@ int mgx_set_field(int lev, int field, const double *host) {
     HIPCHK(hipMemcpyAsync(S.ref_scratch, host, 8 * n3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
     for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 0);
     mgxs_pivots(S.stream, &L.v);
+    L.v.zy = L.v.zx = nullptr;  // a user-supplied matrix is used as stored
     S.have_matrix = true;
   } else if (!field_ptr(L, field, &a, &n)) {
     HIPCHK(hipMemcpyAsync(a, host, n * sizeof(double), hipMemcpyHostToDevice, S.stream));

@@ -17,6 +17,7 @@ struct LevView {
   double *bet;      // reciprocal pivots of the column tridiagonal (tridiag's `bet`, mg_relax.f90:322-327)
   double *gam;      // tridiag's `gam(k)` (mg_relax.f90:325)
   double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
+  double *zy, *zx;  // slopes ZY, ZX (JS layout) for the matrix-free cross terms; nullptr = use the stored slots
 };
 
 __host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }

@@ -215,7 +215,126 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 #undef NB_USE
 }
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-free cross terms.  Away from the special k=1 diagonals, slots 3,5,6,8 are sums of two slope values:
+//   cA3(k,j,i) =  qrt*(ZY(k+1,j,i) + ZY(k,j-1,i))     cA5(k,j,i) = -qrt*(ZY(k-1,j,i) + ZY(k,j-1,i))
+//   cA6(k,j,i) =  qrt*(ZX(k+1,j,i) + ZX(k,j,i-1))     cA8(k,j,i) = -qrt*(ZX(k-1,j,i) + ZX(k,j,i-1))
+// (mg_define_matrix.f90:357-359,397-399,519-555,584-606) with ZY = ((hlf*(zr(k,j+1,i)-zr(k,j-1,i)))/dy)*dx and
+// ZX likewise in i.  A column update needs slots 3,5 of itself AND of its j+1 neighbour (6,8: i+1): four stored
+// values per direction, but only three slope values (own column window + one row of each neighbour).  Rebuilding
+// the four coefficients in registers with the reference's own expression gives bit-identical values and removes
+// 2 of the 19 streams of the colour pass (16 B per updated cell).  Slots 2,4,7, the pivots and the k=1 diagonal
+// terms stay stored.  Used when the matrix came from define_matrices (not after mgx_set_field(cA)).
+// ------------------------------------------------------------------------------------------------
 template <int NZ, bool REAL, bool SNAP, int D>
+__device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph) {
+  int c, jm, jp;
+  if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+  else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+  const long long RS = L.RS;
+  double *__restrict__ p = L.p;
+  const double *__restrict__ b = L.b;
+  const double *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
+               *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet,
+               *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
+  const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+  const double qrt = 0.25;
+
+  constexpr int RN = D + 2;  // rows k .. k+1+D are live at iteration k (row k is still read after the look-ahead load is issued)
+  constexpr int RO = D + 2;  // own rows are needed one row early (zy(k+1), zx(k+1))
+  double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
+  double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
+  double x[NZ], g[NZ];
+
+#define NB_LOAD(q)                                                               \
+  if ((q) <= NZ) {                                                               \
+    const long long ro_ = (long long)((q)-1) * RS; const int s_ = (q) % RN;      \
+    r_pjm[s_] = p[o + ro_ + jm]; r_pim[s_] = p[om + ro_ + c];                    \
+    r_pjp[s_] = p[o + ro_ + jp]; r_pip[s_] = p[op + ro_ + c];                    \
+    r_zyjm[s_] = zy[o + ro_ + jm]; r_zyjp[s_] = zy[o + ro_ + jp];                \
+    r_zxim[s_] = zx[om + ro_ + c]; r_zxip[s_] = zx[op + ro_ + c];                \
+    r_a4[s_] = a4[o + ro_ + jp]; r_a7[s_] = a7[op + ro_ + c];                    \
+  }
+#define OW_LOAD(q)                                                               \
+  if ((q) <= NZ) {                                                               \
+    const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
+    o_b[s_] = b[ko_]; o_a2[s_] = a2[ko_]; o_a4[s_] = a4[ko_]; o_a7[s_] = a7[ko_]; o_bet[s_] = bet[ko_]; \
+    o_zy[s_] = zy[ko_]; o_zx[s_] = zx[ko_];                                      \
+  }
+  double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+  if (REAL) {
+    const double *__restrict__ q1 = SNAP ? L.p1 : p;
+    const long long s = SNAP ? (long long)i * RS : o, sm = SNAP ? s - RS : om, sp = SNAP ? s + RS : op;
+    d1 = q1[sm + jp]; d2 = q1[sp + jm]; d3 = q1[sm + jm]; d4 = q1[sp + jp];
+    e1 = a5[o + c]; e2 = a5[op + jm]; e3 = a8[o + c]; e4 = a8[op + jp];
+  }
+#pragma unroll
+  for (int q = 1; q <= 1 + D; q++) { NB_LOAD(q) }
+#pragma unroll
+  for (int q = 1; q <= 1 + D; q++) { OW_LOAD(q) }
+
+  // three-row windows (k-1, k, k+1) of the neighbour columns' p and of the own slopes
+  double pjm_m = 0, pjm_0 = r_pjm[1 % RN], pjm_p = 0, pim_m = 0, pim_0 = r_pim[1 % RN], pim_p = 0;
+  double pjp_m = 0, pjp_0 = r_pjp[1 % RN], pjp_p = 0, pip_m = 0, pip_0 = r_pip[1 % RN], pip_p = 0;
+  double zy_m = 0, zy_0 = o_zy[1 % RO], zy_p = 0, zx_m = 0, zx_0 = o_zx[1 % RO], zx_p = 0;
+  double xv = 0.0, betp = 0.0;
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) {
+    NB_LOAD(k + 1 + D)
+    OW_LOAD(k + 1 + D)
+    if (k < NZ) {
+      const int s1 = (k + 1) % RN, t1 = (k + 1) % RO;
+      pjm_p = r_pjm[s1]; pim_p = r_pim[s1]; pjp_p = r_pjp[s1]; pip_p = r_pip[s1];
+      zy_p = o_zy[t1]; zx_p = o_zx[t1];
+    }
+    const int s = k % RO, n = k % RN;
+    const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n];
+    if (k > 1) g[k - 1] = o_a2[s] * betp;
+    betp = o_bet[s];
+    double rhs;
+    if (k == 1) {
+      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zyjp + zy_p)) * pjp_p
+                   - (qrt * (zx_p + zxim)) * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zxip + zx_p)) * pip_p;
+      if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4;
+      xv = rhs * o_bet[s];
+    } else if (k < NZ) {
+      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0
+                   - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
+                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0
+                   - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
+      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+    } else {
+      rhs = o_b[s] - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m
+                   - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zx_m + zxim)) * pim_m;
+      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+    }
+    x[k - 1] = xv;
+    pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
+    pjp_m = pjp_0; pjp_0 = pjp_p; pip_m = pip_0; pip_0 = pip_p;
+    zy_m = zy_0; zy_0 = zy_p; zx_m = zx_0; zx_0 = zx_p;
+  }
+#pragma unroll
+  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
+
+  const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
+  const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  const int cS = L.EO, cN = jpos(L, L.ny + 1);
+  const long long oW = 0, oE = (long long)(L.nx + 1) * L.plane;
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) {
+    const long long ro = (long long)(k - 1) * RS;
+    const double v = x[k - 1];
+    p[o + ro + c] = v;
+    if (mS) p[o + ro + cS] = v;
+    if (mN) p[o + ro + cN] = v;
+    if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
+    if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
+  }
+#undef NB_LOAD
+#undef OW_LOAD
+}
+
+template <int NZ, bool REAL, bool SNAP, int D, bool MF>
 __global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
   const int jh = blockIdx.x * WAVE + threadIdx.x;
   const int ipl = blockIdx.y;
@@ -223,7 +342,8 @@ __global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
-  relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
+  if (MF) relax_col_mf<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
+  else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }
 
 // Lexicographic Gauss-Seidel (mg_relax.f90:116-148) on the device, EXACTLY: column (j,i) of the reference's
@@ -342,6 +462,77 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
   }
   if (!want_norm) return;
   // block reduction: wave shuffle, then LDS across the waves of the block (deterministic order)
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double red[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6;
+  if ((tid & 63) == 0) red[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    for (int q = 0; q < nw; q++) s += red[q];
+    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// residual with matrix-free cross terms (see relax_col_mf): 18 streams per cell instead of 22
+template <bool REAL>
+__global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int jodd = blockIdx.z == 0;
+  double acc = 0.0;
+  if (jh < (L.ny >> 1) && i <= L.nx) {
+    int c, jm, jp;
+    if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+    else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+    const long long RS = L.RS;
+    const int nz = L.nz;
+    const double *__restrict__ p = L.p, *__restrict__ b = L.b;
+    double *__restrict__ r = L.r;
+    const double *__restrict__ a1 = L.cA[0], *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
+                 *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7], *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
+    const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+    const double qrt = 0.25;
+    double pc_m = 0, pc_0, pc_p, pjm_m = 0, pjm_0, pjm_p, pim_m = 0, pim_0, pim_p, pjp_m = 0, pjp_0, pjp_p, pip_m = 0, pip_0, pip_p;
+    double zy_m = 0, zy_0, zy_p, zx_m = 0, zx_0, zx_p, a2_0, a2_p;
+#define LOAD_WIN(q, PC, PJM, PIM, PJP, PIP, ZY, ZX, A2)                        \
+  { const long long ro = (long long)((q)-1) * RS;                              \
+    PC = p[o + ro + c]; PJM = p[o + ro + jm]; PIM = p[om + ro + c]; PJP = p[o + ro + jp]; PIP = p[op + ro + c]; \
+    ZY = zy[o + ro + c]; ZX = zx[o + ro + c]; A2 = a2[o + ro + c]; }
+    LOAD_WIN(1, pc_0, pjm_0, pim_0, pjp_0, pip_0, zy_0, zx_0, a2_0)
+    LOAD_WIN(2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
+    for (int k = 1; k <= nz; k++) {
+      const long long ro = (long long)(k - 1) * RS, ko = o + ro + c;
+      const double zyjm = zy[o + ro + jm], zyjp = zy[o + ro + jp], zxim = zx[om + ro + c], zxip = zx[op + ro + c];
+      const double a4jp = a4[o + ro + jp], a7ip = a7[op + ro + c];
+      double rr;
+      if (k == 1) {
+        rr = b[ko] - a1[ko] * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - a4[ko] * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - a7[ko] * pim_0 - a7ip * pip_0
+                   - (-qrt * (zxip + zx_p)) * pip_p;
+        if (REAL)
+          rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
+      } else if (k < nz) {
+        rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
+                   - a4[ko] * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
+                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - a7[ko] * pim_0 - a7ip * pip_0
+                   - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
+      } else {
+        rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - a4[ko] * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - a7[ko] * pim_0 - a7ip * pip_0
+                   - (-qrt * (zx_m + zxim)) * pim_m;
+      }
+      r[ko] = rr;
+      acc = acc + rr * rr;
+      pc_m = pc_0; pc_0 = pc_p; pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
+      pjp_m = pjp_0; pjp_0 = pjp_p; pip_m = pip_0; pip_0 = pip_p;
+      zy_m = zy_0; zy_0 = zy_p; zx_m = zx_0; zx_0 = zx_p; a2_0 = a2_p;
+      if (k + 2 <= nz) LOAD_WIN(k + 2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
+    }
+#undef LOAD_WIN
+  }
+  if (!want_norm) return;
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ double red[16];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6;
@@ -594,9 +785,16 @@ template <int NZ>
 static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   dim3 blk(WAVE), grd((L->ny / 2 + WAVE - 1) / WAVE, nplanes);
   constexpr int D = NZ >= 8 ? 3 : 1;
-  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  const bool mf = L->zy != nullptr && NZ >= 16;  // matrix-free cross terms on the bandwidth-bound levels
+  if (mf) {
+    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+    return;
+  }
+  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
 }
 
 extern "C" {
@@ -652,7 +850,10 @@ void mgxk_snapshot_k1(hipStream_t st, const LevView *L) {
 int mgxk_residual_nblocks(const LevView *L) { dim3 g = col_grid(L->ny / 2, L->nx, 2); return g.x * g.y * g.z; }
 void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *out, int real, int want_norm) {
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
-  if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm);
+  if (L->zy != nullptr && L->nz >= 3) {
+    if (real) hipLaunchKernelGGL((k_residual_mf<true>), grd, blk, 0, st, *L, partial, want_norm);
+    else hipLaunchKernelGGL((k_residual_mf<false>), grd, blk, 0, st, *L, partial, want_norm);
+  } else if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm);
   else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm);
   if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }

@@ -220,6 +220,18 @@ __global__ void k_cA_diag(GeoView G) {
                    - CA(6, k - 1, j, i + 1) - CA(8, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i);
 }
 
+// slopes for the matrix-free cross terms of the smoother, in the JS layout, with the reference's inline expression
+// ( hlf * (zr(k,j+1,i)-zr(k,j-1,i)) / dy(j,i) ) * dx(j,i)   (mg_define_matrix.f90:358, 398)
+__global__ void k_slopes_js(GeoView G, LevView L) {
+  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  const double hlf = 0.5;
+  const long long o = (long long)i * L.plane + jpos(L, j);
+  for (int k = 1; k <= nz; k++) {
+    L.zy[o + (long long)(k - 1) * L.RS] = (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
+    L.zx[o + (long long)(k - 1) * L.RS] = (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
+  }
+}
+
 // tridiagonal pivots of every interior column (mg_relax.f90:322-327): bet(1)=1/d(1);
 // gam(k)=dd(k-1)*bet ; bet(k)=1/(d(k)-dd(k-1)*gam(k)) with d=cA(1,:), dd(k-1)=cA(2,k)
 __global__ void k_pivots(LevView L) {
@@ -397,6 +409,7 @@ void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1) {
   hipLaunchKernelGGL(k_cA_offdiag, cgrid(G->ny + 2, G->nx + 1), CBLK, 0, st, *G);
   hipLaunchKernelGGL(k_cA_diag, cgrid(G->ny, G->nx), CBLK, 0, st, *G);
 }
+void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
 void mgxs_rhs_uf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_uf, cgrid(G->ny, G->nx + 1), CBLK, 0, st, *G, *M, fx); }
 void mgxs_rhs_vf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_vf, cgrid(G->ny + 1, G->nx), CBLK, 0, st, *G, *M, fx); }

@@ -223,6 +223,24 @@ def test_ragged_and_minimum_sizes(mg):
         assert np.array_equal(mg.grid(1).p, o.field("p")), dims
 
 
+def test_stored_coefficient_path_after_set_field(mg):
+    # mgx_set_field(cA) switches the smoother from the matrix-free cross terms back to the stored slots 3,5,6,8:
+    # feeding the same matrix back must not change a single bit, and a modified matrix must be honoured
+    nx, ny, nz = 32, 32, 16
+    o = _setup(mg, nx, ny, nz)
+    r = np.random.default_rng(8)
+    g = mg.grid(1)
+    p = r.standard_normal(g._shape("p")); b = r.standard_normal(g._shape("b"))
+    cA = g.get("cA")
+    for scale in (1.0, 1.5):
+        cA2 = cA.copy(); cA2[..., 2] *= scale; cA2[..., 5] *= scale
+        g.set("cA", cA2); o.field("cA")[...] = cA2
+        g.set("p", p); g.set("b", b); mg.fill_halo(1, "p")
+        o.field("p")[...] = p; o.field("b")[...] = b; o.fill_halo(1, "p")
+        mg.relax(1, 1); o.relax(1, 1)
+        assert np.array_equal(g.get("p"), o.field("p")), scale
+
+
 def test_gauss_seidel_exact(mg):
     # relax_method='GS' (mg_relax.f90:116-148): lexicographic order reproduced exactly by hyperplane launches
     o = _setup(mg, 32, 16, 8, relax_method="GS", solver_prec=1e-8)
