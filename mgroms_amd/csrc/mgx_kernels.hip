@@ -6,6 +6,8 @@
 //
 // Thread mapping everywhere: one lane = one (j,i) column, lanes run along the unit-stride half-row of
 // the JS layout (mgx_internal.h), so every global access of a wave is one contiguous 512-byte run.
+#include <cstdlib>
+
 #include "mgx_internal.h"
 
 #define WAVE 64
@@ -335,9 +337,19 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 }
 
 template <int NZ, bool REAL, bool SNAP, int D, bool MF>
-__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
-  const int jh = blockIdx.x * WAVE + threadIdx.x;
-  const int ipl = blockIdx.y;
+__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
+  // XCD-aware block -> (j-chunk, plane) map.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), each
+  // with its own 4 MB L2.  Give every XCD a contiguous range of planes: the pass over plane i and the pass over plane
+  // i+2 both read p and the slopes of plane i+1, and now meet in the same L2 at about the same time (speed only;
+  // any placement gives the same result).
+  int bx, ipl;
+  if (gx < 0) { gx = -gx; ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }  // MGX_NO_XCD=1 (A/B measurements)
+  else if ((nplanes & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    ipl = xcd * (nplanes >> 3) + local / gx;
+    bx = local - (local / gx) * gx;
+  } else { ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }
+  const int jh = bx * WAVE + threadIdx.x;
   if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
@@ -783,18 +795,20 @@ static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3
 
 template <int NZ>
 static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
-  dim3 blk(WAVE), grd((L->ny / 2 + WAVE - 1) / WAVE, nplanes);
+  static const bool noxcd = getenv("MGX_NO_XCD") != nullptr;
+  const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE, gx = noxcd ? -gx0 : gx0;
+  dim3 blk(WAVE), grd(gx0 * nplanes);
   constexpr int D = NZ >= 8 ? 3 : 1;
   const bool mf = L->zy != nullptr && NZ >= 16;  // matrix-free cross terms on the bandwidth-bound levels
   if (mf) {
-    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
     return;
   }
-  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
-  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
 }
 
 extern "C" {
