@@ -30,10 +30,10 @@ int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_residual_nblocks(const LevView *);
-void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int);
+void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
-void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *);
-void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int);
+void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides);
+void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_pack(hipStream_t, const LevView *, double *, double *, int, int);
@@ -327,8 +327,9 @@ int relax(int lev, int nsweeps) {
 // so neither the reduction nor the all-reduce is issued.
 int residual(int lev, double *res) {
   Level &L = S.lev[lev - 1];
-  mgxk_residual(S.stream, &L.v, S.d_partial, S.d_scalar, S.real, res != nullptr); S.n_launch += res ? 2 : 1;
-  CHK(fill_halo_js(L, L.v.r));
+  const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
+  mgxk_residual(S.stream, &L.v, S.d_partial, S.d_scalar, S.real, res != nullptr, ph); S.n_launch += res ? 2 : 1;
+  CHK(fill_halo_js(L, L.v.r, true));  // the kernel wrote the physical mirrors of r
   if (res) { double s; CHK(global_sum(L, &s)); *res = sqrt(s); }
   return 0;
 }
@@ -336,10 +337,11 @@ int residual(int lev, double *res) {
 // mg_intergrids.f90:16-72
 int fine2coarse(int lev) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  const Sides phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0}, none = {0, 0, 0, 0};
   if (!C.gather) {
-    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b); S.n_launch++;
+    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc); S.n_launch++;
   } else {
-    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b); S.n_launch++;
+    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none); S.n_launch++;
     mgxk_block_to_ref(S.stream, &C.vs, C.vs.b, C.blk); S.n_launch++;
     const int Ng = C.nz * (C.vs.ny + 2) * (C.vs.nx + 2);
     if (!S.ag) return fail("a gather is needed but mgx_set_comm was not called");
@@ -348,7 +350,7 @@ int fine2coarse(int lev) {
       mgxk_gather_place(S.stream, &C.v, C.v.b, C.gbuf + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx); S.n_launch++;
     }
   }
-  CHK(fill_halo_js(C, C.v.b));
+  CHK(fill_halo_js(C, C.v.b, !C.gather));
   HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
   return 0;
 }
@@ -356,16 +358,17 @@ int fine2coarse(int lev) {
 // mg_intergrids.f90:167-228
 int coarse2fine(int lev) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0};
   if (!C.gather) {
-    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf); S.n_launch++;
   } else {
     mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
-    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf); S.n_launch++;
   }
-  CHK(fill_halo_js(F, F.v.r));
+  CHK(fill_halo_js(F, F.v.r, true));
   // p = p + r over the whole array: the interior was updated by the kernel; the halo of p + halo of r
   // equals the halo fill of the updated p (both are images of the same interior cells)
-  CHK(fill_halo_js(F, F.v.p));
+  CHK(fill_halo_js(F, F.v.p, true));
   return 0;
 }
 

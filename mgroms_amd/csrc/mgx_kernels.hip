@@ -12,6 +12,20 @@
 
 #define WAVE 64
 
+// store the physical-boundary images of an interior value (homogeneous Neumann mirror incl. the corner where two
+// physical sides meet, mg_mpi_exchange.f90:509-537,552-597): lets the producing kernel fill its own halo
+__device__ __forceinline__ void mirror_store(const LevView &L, double *__restrict__ a, const long long ro, const int j, const int i,
+                                             const int c, const double v, const Sides ph) {
+  const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  if (!(mS | mN | mW | mE)) return;
+  const int cS = L.EO, cN = jpos(L, L.ny + 1);
+  const long long o = (long long)i * L.plane + ro, oW = ro, oE = (long long)(L.nx + 1) * L.plane + ro;
+  if (mS) a[o + cS] = v;
+  if (mN) a[o + cN] = v;
+  if (mW) { a[oW + c] = v; if (mS) a[oW + cS] = v; if (mN) a[oW + cN] = v; }
+  if (mE) { a[oE + c] = v; if (mS) a[oE + cS] = v; if (mN) a[oE + cN] = v; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // z-line smoother, one colour pass.  mg_relax.f90:237-305 (relax_3D_8_heart) + :308-334 (tridiag).
 // Columns of one colour never read each other (four-colour), or only through the k=1 horizontal
@@ -413,10 +427,20 @@ __global__ void k_snapshot_k1(LevView L) {
 // gridDim.z = 2: z = 0 handles the odd-j half-rows, z = 1 the even-j ones.
 // ------------------------------------------------------------------------------------------------
 template <bool REAL>
-__global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict__ partial, int want_norm) {
-  const int jh = blockIdx.x * WAVE + threadIdx.x;
-  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-  const int jodd = blockIdx.z == 0;
+__global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph) {
+  // 1-D grid of gx*gy*2 blocks; XCD-aware map (see k_relax_nz): each XCD owns a contiguous range of plane groups,
+  // and the two j-parities of a plane group run back to back on the same XCD (they read the same rows)
+  int bx, by, bz;
+  {
+    const int per = gx * 2;
+    int grp, local;
+    if ((gy & 7) == 0) { const int xcd = blockIdx.x & 7; local = blockIdx.x >> 3; grp = xcd * (gy >> 3) + local / per; local -= (local / per) * per; }
+    else { grp = blockIdx.x / per; local = blockIdx.x - grp * per; }
+    by = grp; bz = local / gx; bx = local - bz * gx;
+  }
+  const int jh = bx * WAVE + threadIdx.x;
+  const int i = 1 + by * blockDim.y + threadIdx.y;
+  const int jodd = bz == 0;
   double acc = 0.0;
   if (jh < (L.ny >> 1) && i <= L.nx) {
     int c, jm, jp;
@@ -449,7 +473,9 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
                 - a6[o + c] * pim_p - a7[o + c] * pim_0 - n7_0 - n8_p;
     if (REAL)
       rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
+    const int jcol = jodd ? 2 * jh + 1 : 2 * jh + 2;
     r[o + c] = rr;
+    mirror_store(L, r, 0, jcol, i, c, rr, ph);
     acc = acc + rr * rr;
     for (int k = 2; k <= nz - 1; k++) {  // (:484-496)
       pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p; pc_m = pc_0; pc_0 = pc_p; a2_0 = a2_p;
@@ -459,6 +485,7 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
       rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - a2_p * pc_p - a3[ko] * pjm_p - m3_m - a4[ko] * pjm_0 - m4_0
                  - a5[ko] * pjm_m - m5_p - a6[ko] * pim_p - n6_m - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m - n8_p;
       r[ko] = rr;
+      mirror_store(L, r, (long long)(k - 1) * RS, jcol, i, c, rr, ph);
       acc = acc + rr * rr;
     }
     {  // k = nz (:498-509)
@@ -468,6 +495,7 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
       rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - m3_m - a4[ko] * pjm_0 - m4_0 - a5[ko] * pjm_m - n6_m
                  - a7[ko] * pim_0 - n7_0 - a8[ko] * pim_m;
       r[ko] = rr;
+      mirror_store(L, r, (long long)(nz - 1) * RS, jcol, i, c, rr, ph);
       acc = acc + rr * rr;
     }
 #undef LOAD_ROW
@@ -483,16 +511,26 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
     double s = 0.0;
     const int nw = (blockDim.x * blockDim.y + 63) >> 6;
     for (int q = 0; q < nw; q++) s += red[q];
-    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    partial[blockIdx.x] = s;
   }
 }
 
 // residual with matrix-free cross terms (see relax_col_mf): 18 streams per cell instead of 22
 template <bool REAL>
-__global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm) {
-  const int jh = blockIdx.x * WAVE + threadIdx.x;
-  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-  const int jodd = blockIdx.z == 0;
+__global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph) {
+  // 1-D grid of gx*gy*2 blocks; XCD-aware map (see k_relax_nz): each XCD owns a contiguous range of plane groups,
+  // and the two j-parities of a plane group run back to back on the same XCD (they read the same rows)
+  int bx, by, bz;
+  {
+    const int per = gx * 2;
+    int grp, local;
+    if ((gy & 7) == 0) { const int xcd = blockIdx.x & 7; local = blockIdx.x >> 3; grp = xcd * (gy >> 3) + local / per; local -= (local / per) * per; }
+    else { grp = blockIdx.x / per; local = blockIdx.x - grp * per; }
+    by = grp; bz = local / gx; bx = local - bz * gx;
+  }
+  const int jh = bx * WAVE + threadIdx.x;
+  const int i = 1 + by * blockDim.y + threadIdx.y;
+  const int jodd = bz == 0;
   double acc = 0.0;
   if (jh < (L.ny >> 1) && i <= L.nx) {
     int c, jm, jp;
@@ -536,6 +574,7 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
                    - (-qrt * (zx_m + zxim)) * pim_m;
       }
       r[ko] = rr;
+      mirror_store(L, r, ro, jodd ? 2 * jh + 1 : 2 * jh + 2, i, c, rr, ph);
       acc = acc + rr * rr;
       pc_m = pc_0; pc_0 = pc_p; pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
       pjp_m = pjp_0; pjp_0 = pjp_p; pip_m = pip_0; pip_0 = pip_p;
@@ -554,7 +593,7 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
     double s = 0.0;
     const int nw = (blockDim.x * blockDim.y + 63) >> 6;
     for (int q = 0; q < nw; q++) s += red[q];
-    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    partial[blockIdx.x] = s;
   }
 }
 
@@ -599,7 +638,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
 // `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst) {
+__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (j2 > C.ny || i2 > C.nx) return;
@@ -613,6 +652,7 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
     const double z = x[o0 + r0 + po] + x[o1 + r0 + po] + x[o0 + r0 + pe] + x[o1 + r0 + pe]
                    + x[o0 + r1 + po] + x[o1 + r1 + po] + x[o0 + r1 + pe] + x[o1 + r1 + pe];
     dst[oc + (long long)(k2 - 1) * C.RS] = z;
+    mirror_store(C, dst, (long long)(k2 - 1) * C.RS, j2, i2, jpos(C, j2), z, ph);
   }
 }
 
@@ -622,7 +662,7 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
 // One lane = one coarse column = 2x2 fine columns.  `src` is the coarse p (or the split block).
 // ------------------------------------------------------------------------------------------------
 template <bool LINEAR>
-__global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc) {
+__global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc, Sides ph) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int k2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   const int i2 = 1 + blockIdx.z;
@@ -636,7 +676,9 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
   double *__restrict__ pf = F.p;
   const int nz = C.nz;
 #define XC(kk, JJ, QQ) xc[QQ + (long long)((kk)-1) * C.RS + JJ]
-#define PUT(k, OO, PP, val) { const long long t_ = OO + (long long)((k)-1) * F.RS + PP; const double v_ = (val); rf[t_] = v_; pf[t_] = pf[t_] + v_; }
+#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = pf[t_] + v_; rf[t_] = v_; pf[t_] = w_; \
+    const int jf_ = (PP == po) ? 2 * j2 - 1 : 2 * j2, if_ = (OO == o0) ? i : i + 1; \
+    mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
   if (!LINEAR) {
     const double v = XC(k2, c0, q0);
     const int k = 2 * k2 - 1;
@@ -793,12 +835,11 @@ __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, do
 // ------------------------------------------------------------------------------------------------
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
 
-template <int NZ>
-static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+template <int NZ, int D>
+static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   static const bool noxcd = getenv("MGX_NO_XCD") != nullptr;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE, gx = noxcd ? -gx0 : gx0;
   dim3 blk(WAVE), grd(gx0 * nplanes);
-  constexpr int D = NZ >= 8 ? 3 : 1;
   const bool mf = L->zy != nullptr && NZ >= 16;  // matrix-free cross terms on the bandwidth-bound levels
   if (mf) {
     if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
@@ -809,6 +850,21 @@ static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep,
   if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
   else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
   else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+}
+template <int NZ>
+static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+  // look-ahead depth D (rows of loads in flight): 3 for the long columns; the short ones (<= 16 levels) are
+  // latency-bound on few waves and take everything they can hold
+  constexpr int D = NZ >= 32 ? 3 : (NZ >= 8 ? 7 : 1);
+#ifdef MGX_TUNE_D
+  if (NZ == 64) {
+    static const int dd = getenv("MGX_D") ? atoi(getenv("MGX_D")) : 3;
+    if (dd == 2) return launch_relax_nz_d<NZ, 2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
+    if (dd == 4) return launch_relax_nz_d<NZ, 4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
+    if (dd == 5) return launch_relax_nz_d<NZ, 5>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
+  }
+#endif
+  launch_relax_nz_d<NZ, D>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
 }
 
 extern "C" {
@@ -862,28 +918,29 @@ void mgxk_snapshot_k1(hipStream_t st, const LevView *L) {
   hipLaunchKernelGGL(k_snapshot_k1, dim3((L->RS + 255) / 256, L->nx + 2), dim3(256), 0, st, *L);
 }
 int mgxk_residual_nblocks(const LevView *L) { dim3 g = col_grid(L->ny / 2, L->nx, 2); return g.x * g.y * g.z; }
-void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *out, int real, int want_norm) {
-  dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
+void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *out, int real, int want_norm, Sides ph) {
+  dim3 blk(WAVE, 4), g3 = col_grid(L->ny / 2, L->nx, 2), grd(g3.x * g3.y * 2);
+  const int gx = g3.x, gy = g3.y;
   if (L->zy != nullptr && L->nz >= 3) {
-    if (real) hipLaunchKernelGGL((k_residual_mf<true>), grd, blk, 0, st, *L, partial, want_norm);
-    else hipLaunchKernelGGL((k_residual_mf<false>), grd, blk, 0, st, *L, partial, want_norm);
-  } else if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm);
-  else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm);
-  if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
+    if (real) hipLaunchKernelGGL((k_residual_mf<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
+    else hipLaunchKernelGGL((k_residual_mf<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
+  } else if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
+  else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
+  if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)grd.x, out);
 }
 void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *partial, double *out) {
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
   hipLaunchKernelGGL(k_sumsq, grd, blk, 0, st, *L, a, partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }
-void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst) {
-  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst);
+void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph) {
+  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph);
 }
-void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear) {
+void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph) {
   const int by = C->nz >= 4 ? 4 : C->nz;
   dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
-  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src);
-  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src);
+  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src, ph);
+  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src, ph);
 }
 void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
   const int n = L->nx + L->ny + 1;
