@@ -835,6 +835,57 @@ __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, do
 // ------------------------------------------------------------------------------------------------
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
 
+// Coarsest-level solve entirely out of LDS: when p, b, slots 2..8 and the pivots of a level fit in 64 KB (16x16x2:
+// 57 KB), ONE workgroup copies them in (compact JS layout), runs all nsweeps x colours with the same column routine
+// (its pointers now address LDS), and writes p back.  relax(nlevs, ns_coarsest=40) = 160 dependent colour passes:
+// ~0.3 us each from LDS instead of ~1.1 us through L2 (and ~5 us as separate launches).
+template <int NZ, bool REAL>
+__global__ __launch_bounds__(256) void k_relax_tiny(LevView G, int nsweeps, int method, Sides ph) {
+  extern __shared__ double lds[];
+  LevView L = G;
+  L.EO = 0; L.HO = (G.ny >> 1) + 1; L.RS = G.ny + 2; L.plane = (long long)NZ * L.RS;
+  const int n3 = (G.nx + 2) * (int)L.plane;
+  double *base = lds;
+  L.p = base; base += n3; L.b = base; base += n3;
+  for (int q = 1; q < 8; q++) { L.cA[q] = base; base += n3; }
+  L.cA[0] = nullptr; L.bet = base; base += n3; L.gam = nullptr; L.zy = L.zx = nullptr;
+  L.p1 = base;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int t = tid; t < n3; t += nth) {  // copy in: compact index t -> (i,k,j) -> padded global index
+    const int i = t / (int)L.plane, rem = t - i * (int)L.plane, k = rem / L.RS, pos = rem - k * L.RS;
+    const int j = pos < L.HO ? 2 * pos : 2 * (pos - L.HO) + 1;
+    const long long gidx = (long long)i * G.plane + (long long)k * G.RS + jpos(G, j);
+    L.p[t] = G.p[gidx]; L.b[t] = G.b[gidx]; L.bet[t] = G.bet[gidx];
+    for (int q = 1; q < 8; q++) L.cA[q][t] = G.cA[q][gidx];
+  }
+  __syncthreads();
+  const int nyh = L.ny >> 1;
+  for (int it = 0; it < nsweeps; it++) {
+    const int ncolour = method == 2 ? 4 : 2;
+    for (int cidx = 0; cidx < ncolour; cidx++) {
+      if (method == 1 && REAL) {
+        for (int t = tid; t < (L.nx + 2) * L.RS; t += nth) L.p1[t] = L.p[(t / L.RS) * (int)L.plane + (t % L.RS)];
+        __syncthreads();
+      }
+      const int ncol = method == 2 ? (L.nx >> 1) * nyh : L.nx * nyh;
+      for (int t = tid; t < ncol; t += nth) {
+        const int ipl = t / nyh, jh = t - ipl * nyh;
+        int i, jodd;
+        if (method == 2) { i = 1 + (cidx >> 1) + 2 * ipl; jodd = (cidx & 1) == 0; }
+        else { i = 1 + ipl; jodd = ((i + cidx + 1) & 1) == 0; }
+        if (method == 1) relax_col_nz<NZ, REAL, REAL, 1>(L, i, jh, jodd, ph);
+        else relax_col_nz<NZ, REAL, false, 1>(L, i, jh, jodd, ph);
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = tid; t < n3; t += nth) {  // copy p back (halo included: the column routine kept it mirrored)
+    const int i = t / (int)L.plane, rem = t - i * (int)L.plane, k = rem / L.RS, pos = rem - k * L.RS;
+    const int j = pos < L.HO ? 2 * pos : 2 * (pos - L.HO) + 1;
+    G.p[(long long)i * G.plane + (long long)k * G.RS + jpos(G, j)] = L.p[t];
+  }
+}
+
 template <int NZ, int D>
 static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   static const bool noxcd = getenv("MGX_NO_XCD") != nullptr;
@@ -886,6 +937,19 @@ int mgxk_relax_gs_sweep(hipStream_t st, const LevView *L, int real) {
 
 // one-launch relax of a small level; returns 0 if the level does not qualify
 int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph) {
+  {  // everything in LDS? (11 arrays of the compact level + the k=1 snapshot)
+    static const bool notiny = getenv("MGX_NO_TINY") != nullptr;
+    const size_t n3 = (size_t)(L->nx + 2) * (L->ny + 2) * L->nz, bytes = (11 * n3 + (size_t)(L->nx + 2) * (L->ny + 2)) * sizeof(double);
+    if (!notiny && bytes <= 64 * 1024 && (ph.S && ph.E && ph.N && ph.W) && (L->nz == 2 || L->nz == 4)) {
+      const int ncolt = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
+      const int ntht = ncolt <= 64 ? 64 : 256;
+      if (L->nz == 2) { if (real) hipLaunchKernelGGL((k_relax_tiny<2, true>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph);
+                        else hipLaunchKernelGGL((k_relax_tiny<2, false>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph); }
+      else { if (real) hipLaunchKernelGGL((k_relax_tiny<4, true>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph);
+             else hipLaunchKernelGGL((k_relax_tiny<4, false>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph); }
+      return 1;
+    }
+  }
   const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
   // one CU streams ~25-50 GB/s: worth it only while the level is launch-bound, not bandwidth-bound (measured:
   // 16x16x2 and 32x32x4 win, 64x64x8 loses 2x against separate launches over 256 CUs)
