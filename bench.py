@@ -138,6 +138,27 @@ def main():
     sync()
     fc_rate = nf / (time.perf_counter() - t2)
 
+    counters_main, nlev_main = nhydro.counters(), mg.nlevs()
+    # the reference's default ordering (red-black) on the same workload, for the record (N=1 only)
+    also_rb = None
+    if world == 1 and args.method == "FC":
+        mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
+        mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+        nhydro.compute_rhs(u, v, w)
+        for _ in range(2):
+            mg.Vcycle(1)
+        sync()
+        t3 = time.perf_counter()
+        nrb = max(5, args.steps // 2)
+        for _ in range(nrb):
+            mg.Vcycle(1)
+        sync()
+        rb_ms = (time.perf_counter() - t3) / nrb * 1e3
+        rb_sweep = nhydro.time_relax(1, args.sweep_reps)
+        also_rb = {"vcycles_per_sec": 1e3 / rb_ms, "ms_per_step": rb_ms, "sweep_ms": rb_sweep,
+                   "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "note": "relax_method='RB' (reference default; parallel red-black semantics, DESIGN.md section 2)"}
+
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true>"
@@ -158,7 +179,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"seamount {nx * npx}x{ny * npy}x{nz} ({npx}x{npy} ranks of {nx}x{ny}x{nz}), "
                                    f"relax_method={args.method}, ns_pre=3 ns_post=2 ns_coarsest=40, cmatrix=real, interp=linear",
-                       "levels": mg.nlevs(), "step": "one Vcycle(1)"},
+                       "levels": nlev_main, "step": "one Vcycle(1)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname + " (level-1 colour pass)",
@@ -167,7 +188,8 @@ def main():
             "residual_kernel": {"ms": resid_ms, "GBs": 88 * cells / (resid_ms * 1e-3) / 1e9},
             "fcycle_iterations_per_sec": fc_rate,
             "residual_before": res0, "residual_after": res1,
-            "counters": nhydro.counters(),
+            "counters": counters_main,
+            "also_rb": also_rb,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, nz, args.method)
