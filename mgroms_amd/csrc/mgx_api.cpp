@@ -37,6 +37,7 @@ void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const doubl
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_pack(hipStream_t, const LevView *, double *, double *, int, int);
+void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
 void mgxk_gather_place(hipStream_t, const LevView *, double *, const double *, int, int, int, int);
 void mgxk_block_to_ref(hipStream_t, const LevView *, const double *, double *);
@@ -68,6 +69,7 @@ struct Level {
   double *blk, *gbuf;  // all-gather send / receive (reference layout blocks incl. halo)
   int group[4], ngroup;
   size_t n3js;  // doubles in one JS array
+  bool r_halo_stale = false, b_halo_stale = false;  // deferred neighbour exchanges (multi-rank)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
 };
 
@@ -87,6 +89,7 @@ struct State {
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
   std::vector<void *> allocs;
   int verbose = 1;
+  int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -189,17 +192,18 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
   const int *nb = L.neighb;
   Sides ph = {nb[0] < 0, nb[1] < 0, nb[2] < 0, nb[3] < 0};
   if (!phys_done && (ph.S || ph.E || ph.N || ph.W)) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
-  int n = 0, peer[8], cnt[8], dirs[8];
+  int n = 0, peer[8], cnt[8], present[8];
   double *sb[8], *rb[8];
   for (int d = 0; d < 8; d++) {
+    present[d] = nb[d] >= 0;
     if (nb[d] < 0) continue;
     const int c = L.nz * ((d == 0 || d == 2) ? L.nx : ((d == 1 || d == 3) ? L.ny : 1));
-    mgxk_halo_pack(S.stream, &L.v, a, S.xbuf[d], d, 0); S.n_launch++;
-    peer[n] = nb[d]; cnt[n] = c; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d]; dirs[n] = d; n++;
+    peer[n] = nb[d]; cnt[n] = c; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d]; n++;
   }
   if (n) {
+    mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf, present, 0); S.n_launch++;       // all edges + corners, one launch
     CHK(exchange(n, peer, sb, rb, cnt));
-    for (int q = 0; q < n; q++) { mgxk_halo_pack(S.stream, &L.v, a, rb[q], dirs[q], 1); S.n_launch++; }
+    mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf + 8, present, 1); S.n_launch++;
     int m[4];
     const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
     bool any = false;
@@ -329,7 +333,9 @@ int residual(int lev, double *res) {
   Level &L = S.lev[lev - 1];
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   mgxk_residual(S.stream, &L.v, S.d_partial, S.d_scalar, S.real, res != nullptr, ph); S.n_launch += res ? 2 : 1;
-  CHK(fill_halo_js(L, L.v.r, true));  // the kernel wrote the physical mirrors of r
+  // the kernel wrote the physical mirrors of r; the neighbour part of r's halo is never read by the cycle (restriction
+  // uses interior cells only), so the exchange is deferred until someone asks for r (mgx_get_field / mgx_fill_halo)
+  if (S.exact_halos) CHK(fill_halo_js(L, L.v.r, true)); else L.r_halo_stale = true;
   if (res) { double s; CHK(global_sum(L, &s)); *res = sqrt(s); }
   return 0;
 }
@@ -350,7 +356,8 @@ int fine2coarse(int lev) {
       mgxk_gather_place(S.stream, &C.v, C.v.b, C.gbuf + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx); S.n_launch++;
     }
   }
-  CHK(fill_halo_js(C, C.v.b, !C.gather));
+  // b's halo is not read by relax/residual either: physical mirrors are in place, neighbour exchange deferred
+  if (S.exact_halos || C.gather) CHK(fill_halo_js(C, C.v.b, !C.gather)); else C.b_halo_stale = true;
   HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
   return 0;
 }
@@ -365,7 +372,7 @@ int coarse2fine(int lev) {
     mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
     mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf); S.n_launch++;
   }
-  CHK(fill_halo_js(F, F.v.r, true));
+  if (S.exact_halos) CHK(fill_halo_js(F, F.v.r, true)); else F.r_halo_stale = true;
   // p = p + r over the whole array: the interior was updated by the kernel; the halo of p + halo of r
   // equals the halo fill of the updated p (both are images of the same interior cells)
   CHK(fill_halo_js(F, F.v.p, true));
@@ -698,6 +705,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   HIPCHK(hipStreamSynchronize(S.stream));
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
+  S.exact_halos = getenv("MGX_EXACT_HALOS") ? 1 : 0;
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
@@ -851,6 +859,8 @@ int mgx_get_field(int lev, int field, double *host) {
   double *a; size_t n;
   if (field == MGX_P || field == MGX_B || field == MGX_R) {
     double *js = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : L.v.r);
+    if (field == MGX_R && L.r_halo_stale) { CHK(fill_halo_js(L, L.v.r, true)); L.r_halo_stale = false; }
+    if (field == MGX_B && L.b_halo_stale) { CHK(fill_halo_js(L, L.v.b, true)); L.b_halo_stale = false; }
     mgxk_convert(S.stream, &L.v, js, S.ref_scratch, 1, 0, 1);
     HIPCHK(hipMemcpyAsync(host, S.ref_scratch, n3 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   } else if (field == MGX_CA) {

@@ -782,6 +782,32 @@ __global__ void k_halo_pack(LevView L, double *__restrict__ a, double *__restric
   if (unpack) a[e] = buf[t]; else buf[t] = a[e];
 }
 
+// all present directions in one launch: blockIdx.z = direction (absent ones return), buffers passed by value
+struct HaloBufs { double *b[8]; int present[8]; };
+__global__ void k_halo_pack_all(LevView L, double *__restrict__ a, HaloBufs hb, int unpack) {
+  const int dir = blockIdx.z;
+  if (!hb.present[dir]) return;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  const int nx = L.nx, ny = L.ny;
+  int i, j, n;
+  switch (dir) {
+    case 0: n = nx; i = q + 1; j = unpack ? 0 : 1; break;
+    case 1: n = ny; j = q + 1; i = unpack ? nx + 1 : nx; break;
+    case 2: n = nx; i = q + 1; j = unpack ? ny + 1 : ny; break;
+    case 3: n = ny; j = q + 1; i = unpack ? 0 : 1; break;
+    case 4: n = 1; i = unpack ? 0 : 1; j = unpack ? 0 : 1; break;
+    case 5: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? 0 : 1; break;
+    case 6: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? ny + 1 : ny; break;
+    default: n = 1; i = unpack ? 0 : 1; j = unpack ? ny + 1 : ny; break;
+  }
+  if (q >= n) return;
+  const long long e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
+  const long long t = (long long)q * L.nz + k;
+  double *__restrict__ buf = hb.b[dir];
+  if (unpack) a[e] = buf[t]; else buf[t] = a[e];
+}
+
 // ------------------------------------------------------------------------------------------------
 // layout conversion between the reference layout (k,j,i) k fastest and JS.  dir 0: ref -> JS, 1: JS -> ref
 // ------------------------------------------------------------------------------------------------
@@ -1012,6 +1038,12 @@ void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
 }
 void mgxk_halo_mixed_corners(hipStream_t st, const LevView *L, double *a, int mSW, int mSE, int mNE, int mNW) {
   hipLaunchKernelGGL(k_halo_mixed_corners, dim3((L->nz + 63) / 64), dim3(64), 0, st, *L, a, mSW, mSE, mNE, mNW);
+}
+void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *const *bufs, const int *present, int unpack) {
+  HaloBufs hb;
+  for (int d = 0; d < 8; d++) { hb.b[d] = bufs[d]; hb.present[d] = present[d]; }
+  const int n = L->nx > L->ny ? L->nx : L->ny;
+  hipLaunchKernelGGL(k_halo_pack_all, dim3((n + 63) / 64, L->nz, 8), dim3(64), 0, st, *L, a, hb, unpack);
 }
 void mgxk_halo_pack(hipStream_t st, const LevView *L, double *a, double *buf, int dir, int unpack) {
   const int n = (dir == 0 || dir == 2) ? L->nx : ((dir == 1 || dir == 3) ? L->ny : 1);
