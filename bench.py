@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--method", default="FC", choices=["FC", "RB"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
     args = ap.parse_args()
 
     import torch
@@ -75,11 +77,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.gpus not in PGRID:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         from mgroms_amd.parallel import Comm
         comm = Comm()
 
@@ -116,7 +123,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res1 = mg.compute_residual(1)
