@@ -351,18 +351,20 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 }
 
 template <int NZ, bool REAL, bool SNAP, int D, bool MF>
-__global__ __launch_bounds__(64, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
-  // XCD-aware block -> (j-chunk, plane) map.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one), each
-  // with its own 4 MB L2.  Give every XCD a contiguous range of planes: the pass over plane i and the pass over plane
-  // i+2 both read p and the slopes of plane i+1, and now meet in the same L2 at about the same time (speed only;
-  // any placement gives the same result).
-  int bx, ipl;
-  if (gx < 0) { gx = -gx; ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }  // MGX_NO_XCD=1 (A/B measurements)
-  else if ((nplanes & 7) == 0) {
+__global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
+  // XCD-aware block -> (j-chunk, plane pair) map.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one),
+  // each with its own 4 MB L2.  Give every XCD a contiguous range of planes: the pass over plane i and the pass over
+  // plane i+2 both read p and the slopes of plane i+1.  The two waves of a block take two consecutive planes of the
+  // colour, so those two readers also sit on one CU (speed only; any placement gives the same result).
+  const int npair = (nplanes + blockDim.y - 1) / blockDim.y;
+  int bx, ipr;
+  if (gx < 0) { gx = -gx; ipr = blockIdx.x / gx; bx = blockIdx.x - ipr * gx; }  // MGX_NO_XCD=1 (A/B measurements)
+  else if ((npair & 7) == 0) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    ipl = xcd * (nplanes >> 3) + local / gx;
+    ipr = xcd * (npair >> 3) + local / gx;
     bx = local - (local / gx) * gx;
-  } else { ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }
+  } else { ipr = blockIdx.x / gx; bx = blockIdx.x - ipr * gx; }
+  const int ipl = ipr * blockDim.y + threadIdx.y;
   const int jh = bx * WAVE + threadIdx.x;
   if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
   const int i = i0 + istep * ipl;
@@ -916,7 +918,8 @@ template <int NZ, int D>
 static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   static const bool noxcd = getenv("MGX_NO_XCD") != nullptr;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE, gx = noxcd ? -gx0 : gx0;
-  dim3 blk(WAVE), grd(gx0 * nplanes);
+  static const int by = getenv("MGX_BY") ? atoi(getenv("MGX_BY")) : 2;
+  dim3 blk(WAVE, by), grd(gx0 * ((nplanes + by - 1) / by));
   const bool mf = L->zy != nullptr && NZ >= 16;  // matrix-free cross terms on the bandwidth-bound levels
   if (mf) {
     if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
