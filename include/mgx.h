@@ -118,6 +118,13 @@ int mgx_set_stream(void *hip_stream);
 /* 0 = silent, 1 = the reference's rank-0 prints (parameter block, level table, "ite = ..: res = .. / conv = ..") */
 int mgx_set_verbose(int level);
 
+/* Options (0/1): "warm_start" keep p between solves instead of the cold start of mg_solvers.f90:35;
+ * "tictoc" per-(level,name) timers like mg_tictoc.f90 (HIP events); "exact_halos" exchange the never-read r/b halos
+ * eagerly as the reference does; "verbose". */
+int mgx_set_option(const char *name, int value);
+/* print_tictoc (mg_tictoc.f90:114-153): timer table (seconds, calls per level) to `path` (NULL = "fort.10") */
+int mgx_print_tictoc(const char *path);
+
 /* ---- measurement helpers used by bench.py (timed with HIP events on the solver's stream) ---- */
 /* run `reps` smoother sweeps on level `lev` (reps x relax(lev,1)); *ms = average milliseconds per sweep */
 int mgx_time_relax(int lev, int reps, float *ms);

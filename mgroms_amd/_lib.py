@@ -53,6 +53,8 @@ _SIGS = {
     "mgx_set_comm": (C.c_int, [EXCHANGE_FN, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p]),
     "mgx_set_stream": (C.c_int, [C.c_void_p]),
     "mgx_set_verbose": (C.c_int, [C.c_int]),
+    "mgx_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "mgx_print_tictoc": (C.c_int, [C.c_char_p]),
     "mgx_time_relax": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_time_residual": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_counters": (C.c_int, [C.POINTER(C.c_longlong)]),

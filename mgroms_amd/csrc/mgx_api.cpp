@@ -89,6 +89,8 @@ struct State {
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
   std::vector<void *> allocs;
   int verbose = 1;
+  int warm_start = 0;   // keep p between solves instead of the reference's cold start (mg_solvers.f90:35)
+  int tictoc = 0;       // per-(level,name) GPU timers in the shape of mg_tictoc.f90
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
@@ -295,10 +297,58 @@ int global_sum(const Level &L, double *out) {
   return 0;
 }
 
+
+// ---- mg_tictoc.f90: tic(lev,name) / toc(lev,name) / print_tictoc, timed with HIP events on the solver's stream ----
+struct TicRec { int lev, sub; hipEvent_t e0, e1; };
+std::vector<std::string> tt_names;
+std::vector<TicRec> tt_open, tt_done;
+double tt_time[32][32];
+long long tt_calls[32][32];
+int tt_nblev = 0;
+
+int tt_sub(const char *name) {
+  for (size_t q = 0; q < tt_names.size(); q++) if (tt_names[q] == name) return (int)q;
+  tt_names.push_back(name);
+  return (int)tt_names.size() - 1;
+}
+void tic(int lev, const char *name) {
+  if (!S.tictoc) return;
+  TicRec r; r.lev = lev; r.sub = tt_sub(name);
+  if (r.sub >= 32 || lev > 32) return;
+  hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+  hipEventRecord(r.e0, S.stream);
+  tt_open.push_back(r);
+}
+void toc(int lev, const char *name) {
+  if (!S.tictoc) return;
+  const int sub = tt_sub(name);
+  for (int q = (int)tt_open.size() - 1; q >= 0; q--)
+    if (tt_open[q].lev == lev && tt_open[q].sub == sub) {
+      hipEventRecord(tt_open[q].e1, S.stream);
+      tt_done.push_back(tt_open[q]);
+      tt_open.erase(tt_open.begin() + q);
+      if (lev > tt_nblev) tt_nblev = lev;
+      return;
+    }
+}
+void tt_collect() {
+  if (tt_done.empty()) return;
+  hipStreamSynchronize(S.stream);
+  for (auto &r : tt_done) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tt_time[r.lev - 1][r.sub] += ms * 1e-3; tt_calls[r.lev - 1][r.sub]++; }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  tt_done.clear();
+}
+struct TicScope { int lev; const char *name; TicScope(int l, const char *n) : lev(l), name(n) { tic(l, n); } ~TicScope() { toc(lev, name); } };
+
 // ---- operators ------------------------------------------------------------------------------------
 // mg_relax.f90:16-47 relax ; :151-190 RB ; :193-234 FC
 int relax(int lev, int nsweeps) {
   Level &L = S.lev[lev - 1];
+  TicScope ts(lev, S.method == M_RB ? "relax_3D_8_RB" : (S.method == M_FC ? "relax_3D_8_FC" : "relax_3D_8_GS"));  // mg_relax.f90:128,167,209
+  if (S.tictoc && tt_done.size() > 4096) tt_collect();
   if (S.method == M_GS) {  // exact lexicographic order by hyperplanes; halo fill once per sweep (mg_relax.f90:131-141)
     for (int it = 1; it <= nsweeps; it++) {
       if (!mgxk_relax_gs_sweep(S.stream, &L.v, S.real)) return fail("relax_method='GS': nz=%d has no register-resident kernel (nz must be a power of two <= 64)", L.nz);
@@ -331,6 +381,7 @@ int relax(int lev, int nsweeps) {
 // so neither the reduction nor the all-reduce is issued.
 int residual(int lev, double *res) {
   Level &L = S.lev[lev - 1];
+  TicScope ts(lev, "residual_3D_8");  // mg_relax.f90:367
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   mgxk_residual(S.stream, &L.v, S.d_partial, S.d_scalar, S.real, res != nullptr, ph); S.n_launch += res ? 2 : 1;
   // the kernel wrote the physical mirrors of r; the neighbour part of r's halo is never read by the cycle (restriction
@@ -411,6 +462,7 @@ int vcycle2(int lev1, int lev2) {
 
 // mg_solvers.f90:104-126
 int fcycle() {
+  TicScope ts(1, "Fcycle");  // mg_solvers.f90:108
   for (int lev = 1; lev <= S.nlevs - 1; lev++) {
     CHK(fine2coarse(lev));
     Level &C = S.lev[lev];
@@ -428,7 +480,8 @@ int fcycle() {
 int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist) {
   Level &L = S.lev[0];
   if (S.verbose && S.rank == 0) printf(" - solve p:\n");
-  HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));
+  TicScope ts(1, "solve");  // mg_solvers.f90:45
+  if (!S.warm_start) HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));  // grid(1)%p = 0 (:35)
   mgxk_sumsq(S.stream, &L.v, L.v.b, S.d_partial, S.d_scalar); S.n_launch += 2;
   double bnorm; CHK(global_sum(L, &bnorm)); bnorm = sqrt(bnorm);
   int nite = 0;
@@ -504,6 +557,7 @@ int define_matrices() {
 // mg_compute_rhs.f90:14-379 on the device copies of u,v,w
 int compute_rhs_dev() {
   Level &L = S.lev[0];
+  TicScope ts(1, "compute_rhs");  // nhydro.f90:81
   ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
   HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));
   mgxs_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
@@ -613,10 +667,11 @@ void mgx_clean(void) {
   if (S.stream || S.inited) hipStreamSynchronize(S.stream);
   for (void *q : S.allocs) hipFree(q);
   if (S.h_scalar) hipHostFree(S.h_scalar);
-  hipStream_t st = S.stream; int vb = S.verbose;
+  tt_collect();
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx;
   S = State();
-  S.stream = st; S.verbose = vb; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -705,7 +760,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   HIPCHK(hipStreamSynchronize(S.stream));
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
-  S.exact_halos = getenv("MGX_EXACT_HALOS") ? 1 : 0;
+  if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
+  if (getenv("MGX_TICTOC")) S.tictoc = 1;
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
@@ -826,6 +882,36 @@ int mgx_level_table(int nx, int ny, int nz, int npx, int npy, int rank, int nsma
     memcpy(out + 20 * l, v, sizeof(v)); memcpy(out + 20 * l + 12, L.neighb, 8 * sizeof(int));
   }
   return nl;
+}
+
+int mgx_set_option(const char *name, int value) {
+  if (streq(name, "warm_start")) S.warm_start = value;
+  else if (streq(name, "tictoc")) S.tictoc = value;
+  else if (streq(name, "exact_halos")) S.exact_halos = value;
+  else if (streq(name, "verbose")) S.verbose = value;
+  else return fail("unknown option '%s'", name);
+  return 0;
+}
+
+// print_tictoc (mg_tictoc.f90:114-153): name, total and per-level seconds, then the call counts
+int mgx_print_tictoc(const char *path) {
+  tt_collect();
+  FILE *f = fopen(path ? path : "fort.10", "w");
+  if (!f) return fail("cannot open %s", path ? path : "fort.10");
+  fprintf(f, "%21s%10s", "", "Total");
+  for (int l = 1; l <= tt_nblev; l++) fprintf(f, " %9d", l);
+  fprintf(f, " \n");
+  for (size_t q = 0; q < tt_names.size(); q++) {
+    double tot = 0; long long nc = 0;
+    for (int l = 0; l < tt_nblev; l++) { tot += tt_time[l][q]; nc += tt_calls[l][q]; }
+    fprintf(f, " %20s %9.3E", tt_names[q].c_str(), tot);
+    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %9.3E", tt_time[l][q]);
+    fprintf(f, " \n%21s %9lld", "", nc);
+    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %9lld", tt_calls[l][q]);
+    fprintf(f, " \n");
+  }
+  fclose(f);
+  return 0;
 }
 
 int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }

@@ -44,6 +44,16 @@ def read_nhnamelist(filename="nh_namelist", **overrides):
     return p
 
 
+def set_option(name, value):
+    """warm_start / tictoc / exact_halos / verbose (include/mgx.h: mgx_set_option)."""
+    check(lib().mgx_set_option(name.encode(), int(value)))
+
+
+def print_tictoc(path="fort.10"):
+    """print_tictoc (mg_tictoc.f90:114): per-level timer table of relax / residual / Fcycle / solve / compute_rhs."""
+    check(lib().mgx_print_tictoc(path.encode()))
+
+
 def set_verbose(level):
     check(lib().mgx_set_verbose(int(level)))
 
