@@ -92,7 +92,7 @@ def main():
 
     import mgroms_amd as mg
     from mgroms_amd import nhydro
-    from oracle.mgoracle import seamount_geometry  # synthetic-input generator only (mg_setup_tests.f90:145)
+    from mgroms_amd.testcases import seamount_geometry, resting_column_state
 
     nx, ny, nz = args.size
     npx, npy = PGRID[args.gpus]
@@ -104,7 +104,7 @@ def main():
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
     mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
-    u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
+    u, v, w = resting_column_state(nx, ny, nz)
     nhydro.compute_rhs(u, v, w)
     res0 = mg.compute_residual(1)
 

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 import mgroms_amd as mg  # noqa: E402
 from mgroms_amd import nhydro  # noqa: E402
-from oracle.mgoracle import seamount_geometry  # noqa: E402  (input generator only)
+from mgroms_amd.testcases import seamount_geometry  # noqa: E402
 
 nx, ny, nz = (int(a) for a in sys.argv[1:4])
 method = sys.argv[4] if len(sys.argv) > 4 else "FC"
