@@ -11,6 +11,21 @@
 #include "mgx_internal.h"
 
 #define WAVE 64
+// streams that a pass reads exactly once and nobody re-reads soon: keep them out of the way of the reused lines
+#ifndef MGX_NO_NT
+#define NT_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define NT_LOAD(ptr) (*(ptr))
+#endif
+// same hints chosen at compile time (the one-workgroup kernels re-read their level every sweep: no hint there)
+template <bool NT> __device__ __forceinline__ double ld_stream(const double *p) { return NT ? NT_LOAD(p) : *p; }
+#ifndef MGX_NO_NT2
+#define NT2_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#define NT2_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define NT2_LOAD(ptr) (*(ptr))
+#define NT2_STORE(v, ptr) (*(ptr) = (v))
+#endif
 
 // store the physical-boundary images of an interior value (homogeneous Neumann mirror incl. the corner where two
 // physical sides meet, mg_mpi_exchange.f90:509-537,552-597): lets the producing kernel fill its own halo
@@ -135,6 +150,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
                *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
 
+  constexpr bool ST = D >= 3;  // streaming instantiation (one pass over a big level)
   constexpr int RN = D + 1;  // raw neighbour rows in flight
   constexpr int RO = D + 1;  // raw own rows in flight
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_a3[RN], r_a4[RN], r_a5[RN], r_a6[RN], r_a7[RN], r_a8[RN];
@@ -152,8 +168,8 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = b[ko_]; o_a2[s_] = a2[ko_]; o_a3[s_] = a3[ko_]; o_a4[s_] = a4[ko_]; o_a5[s_] = a5[ko_]; \
-    o_a6[s_] = a6[ko_]; o_a7[s_] = a7[ko_]; o_a8[s_] = a8[ko_]; o_bet[s_] = bet[ko_]; \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a3[s_] = ld_stream<ST>(a3 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a5[s_] = ld_stream<ST>(a5 + ko_); \
+    o_a6[s_] = ld_stream<ST>(a6 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); o_a8[s_] = ld_stream<ST>(a8 + ko_); o_bet[s_] = ld_stream<ST>(bet + ko_); \
   }
   // products of a raw neighbour row (computed when the row is first needed)
 #define NB_USE(q, PJM, PIM, M3, M4, M5, N6, N7, N8)                              \
@@ -274,8 +290,8 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = b[ko_]; o_a2[s_] = a2[ko_]; o_a4[s_] = a4[ko_]; o_a7[s_] = a7[ko_]; o_bet[s_] = bet[ko_]; \
-    o_zy[s_] = zy[ko_]; o_zx[s_] = zx[ko_];                                      \
+    o_b[s_] = NT_LOAD(b + ko_); o_a2[s_] = NT_LOAD(a2 + ko_); o_a4[s_] = NT2_LOAD(a4 + ko_); o_a7[s_] = NT2_LOAD(a7 + ko_); o_bet[s_] = NT_LOAD(bet + ko_); \
+    o_zy[s_] = NT2_LOAD(zy + ko_); o_zx[s_] = NT2_LOAD(zx + ko_);                                      \
   }
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
@@ -340,7 +356,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   for (int k = 1; k <= NZ; k++) {
     const long long ro = (long long)(k - 1) * RS;
     const double v = x[k - 1];
-    p[o + ro + c] = v;
+    NT2_STORE(v, p + o + ro + c);
     if (mS) p[o + ro + cS] = v;
     if (mN) p[o + ro + cN] = v;
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
 #define LOAD_WIN(q, PC, PJM, PIM, PJP, PIP, ZY, ZX, A2)                        \
   { const long long ro = (long long)((q)-1) * RS;                              \
     PC = p[o + ro + c]; PJM = p[o + ro + jm]; PIM = p[om + ro + c]; PJP = p[o + ro + jp]; PIP = p[op + ro + c]; \
-    ZY = zy[o + ro + c]; ZX = zx[o + ro + c]; A2 = a2[o + ro + c]; }
+    ZY = NT2_LOAD(zy + o + ro + c); ZX = NT2_LOAD(zx + o + ro + c); A2 = NT_LOAD(a2 + o + ro + c); }
     LOAD_WIN(1, pc_0, pjm_0, pim_0, pjp_0, pip_0, zy_0, zx_0, a2_0)
     LOAD_WIN(2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
     for (int k = 1; k <= nz; k++) {
@@ -560,22 +576,22 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
       const double a4jp = a4[o + ro + jp], a7ip = a7[op + ro + c];
       double rr;
       if (k == 1) {
-        rr = b[ko] - a1[ko] * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - a4[ko] * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - a7[ko] * pim_0 - a7ip * pip_0
+        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zxip + zx_p)) * pip_p;
         if (REAL)
           rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
       } else if (k < nz) {
-        rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
-                   - a4[ko] * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
-                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - a7[ko] * pim_0 - a7ip * pip_0
+        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
+                   - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
+                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
       } else {
-        rr = b[ko] - a1[ko] * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - a4[ko] * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - a7[ko] * pim_0 - a7ip * pip_0
+        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m;
       }
-      r[ko] = rr;
+      NT2_STORE(rr, r + ko);
       mirror_store(L, r, ro, jodd ? 2 * jh + 1 : 2 * jh + 2, i, c, rr, ph);
       acc = acc + rr * rr;
       pc_m = pc_0; pc_0 = pc_p; pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
