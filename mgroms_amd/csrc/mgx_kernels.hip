@@ -17,13 +17,41 @@
 #else
 #define NT_LOAD(ptr) (*(ptr))
 #endif
+#if defined(MGX_RES_NT) && MGX_RES_NT == 2
+#define RL_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#define RS_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#elif !defined(MGX_RES_NT) || MGX_RES_NT == 1
+// residual: the two j-parities of a plane run in the same launch and read each other's "own" streams -> keep loads
+// cacheable, stream only the r store
+#define RL_LOAD(ptr) (*(ptr))
+#define RS_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define RL_LOAD(ptr) (*(ptr))
+#define RS_STORE(v, ptr) (*(ptr) = (v))
+#endif
+#ifdef MGX_NT3
+#define NT3_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define NT3_LOAD(ptr) (*(ptr))
+#endif
+#ifdef MGX_NT4
+#define NT4_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define NT4_LOAD(ptr) (*(ptr))
+#endif
+__device__ __forceinline__ void st_rt(double *p, double v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ double ld_rt(const double *p, int nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+static inline int level_streams(const LevView *L) { return (double)L->nx * L->ny * L->nz * 72.0 > 256e6; }
 // same hints chosen at compile time (the one-workgroup kernels re-read their level every sweep: no hint there)
 template <bool NT> __device__ __forceinline__ double ld_stream(const double *p) { return NT ? NT_LOAD(p) : *p; }
-#ifndef MGX_NO_NT2
+#ifndef MGX_NO_NT2L
 #define NT2_LOAD(ptr) __builtin_nontemporal_load(ptr)
-#define NT2_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
 #else
 #define NT2_LOAD(ptr) (*(ptr))
+#endif
+#ifndef MGX_NO_NT2S
+#define NT2_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
 #define NT2_STORE(v, ptr) (*(ptr) = (v))
 #endif
 
@@ -150,7 +178,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
                *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
 
-  constexpr bool ST = D >= 3;  // streaming instantiation (one pass over a big level)
+  constexpr bool ST = false;  // stored-slot path: coarser levels / user matrices, which live in the caches
   constexpr int RN = D + 1;  // raw neighbour rows in flight
   constexpr int RO = D + 1;  // raw own rows in flight
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_a3[RN], r_a4[RN], r_a5[RN], r_a6[RN], r_a7[RN], r_a8[RN];
@@ -258,7 +286,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 // 2 of the 19 streams of the colour pass (16 B per updated cell).  Slots 2,4,7, the pivots and the k=1 diagonal
 // terms stay stored.  Used when the matrix came from define_matrices (not after mgx_set_field(cA)).
 // ------------------------------------------------------------------------------------------------
-template <int NZ, bool REAL, bool SNAP, int D>
+template <int NZ, bool REAL, bool SNAP, int D, bool ST>
 __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
@@ -283,15 +311,15 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     const long long ro_ = (long long)((q)-1) * RS; const int s_ = (q) % RN;      \
     r_pjm[s_] = p[o + ro_ + jm]; r_pim[s_] = p[om + ro_ + c];                    \
     r_pjp[s_] = p[o + ro_ + jp]; r_pip[s_] = p[op + ro_ + c];                    \
-    r_zyjm[s_] = zy[o + ro_ + jm]; r_zyjp[s_] = zy[o + ro_ + jp];                \
-    r_zxim[s_] = zx[om + ro_ + c]; r_zxip[s_] = zx[op + ro_ + c];                \
-    r_a4[s_] = a4[o + ro_ + jp]; r_a7[s_] = a7[op + ro_ + c];                    \
+    r_zyjm[s_] = *(zy + o + ro_ + jm); r_zyjp[s_] = *(zy + o + ro_ + jp); \
+    r_zxim[s_] = *(zx + om + ro_ + c); r_zxip[s_] = *(zx + op + ro_ + c); \
+    r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c);      \
   }
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = NT_LOAD(b + ko_); o_a2[s_] = NT_LOAD(a2 + ko_); o_a4[s_] = NT2_LOAD(a4 + ko_); o_a7[s_] = NT2_LOAD(a7 + ko_); o_bet[s_] = NT_LOAD(bet + ko_); \
-    o_zy[s_] = NT2_LOAD(zy + ko_); o_zx[s_] = NT2_LOAD(zx + ko_);                                      \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); o_bet[s_] = ld_stream<ST>(bet + ko_); \
+    o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
@@ -356,7 +384,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   for (int k = 1; k <= NZ; k++) {
     const long long ro = (long long)(k - 1) * RS;
     const double v = x[k - 1];
-    NT2_STORE(v, p + o + ro + c);
+    if (ST) NT2_STORE(v, p + o + ro + c); else p[o + ro + c] = v;
     if (mS) p[o + ro + cS] = v;
     if (mN) p[o + ro + cN] = v;
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
@@ -366,7 +394,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 #undef OW_LOAD
 }
 
-template <int NZ, bool REAL, bool SNAP, int D, bool MF>
+template <int NZ, bool REAL, bool SNAP, int D, bool MF, bool ST>
 __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
   // XCD-aware block -> (j-chunk, plane pair) map.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one),
   // each with its own 4 MB L2.  Give every XCD a contiguous range of planes: the pass over plane i and the pass over
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
-  if (MF) relax_col_mf<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
+  if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
   else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }
 
@@ -445,7 +473,7 @@ __global__ void k_snapshot_k1(LevView L) {
 // gridDim.z = 2: z = 0 handles the odd-j half-rows, z = 1 the even-j ones.
 // ------------------------------------------------------------------------------------------------
 template <bool REAL>
-__global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph) {
+__global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph, int stream) {
   // 1-D grid of gx*gy*2 blocks; XCD-aware map (see k_relax_nz): each XCD owns a contiguous range of plane groups,
   // and the two j-parities of a plane group run back to back on the same XCD (they read the same rows)
   int bx, by, bz;
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
 
 // residual with matrix-free cross terms (see relax_col_mf): 18 streams per cell instead of 22
 template <bool REAL>
-__global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph) {
+__global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph, int stream) {
   // 1-D grid of gx*gy*2 blocks; XCD-aware map (see k_relax_nz): each XCD owns a contiguous range of plane groups,
   // and the two j-parities of a plane group run back to back on the same XCD (they read the same rows)
   int bx, by, bz;
@@ -567,7 +595,7 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
 #define LOAD_WIN(q, PC, PJM, PIM, PJP, PIP, ZY, ZX, A2)                        \
   { const long long ro = (long long)((q)-1) * RS;                              \
     PC = p[o + ro + c]; PJM = p[o + ro + jm]; PIM = p[om + ro + c]; PJP = p[o + ro + jp]; PIP = p[op + ro + c]; \
-    ZY = NT2_LOAD(zy + o + ro + c); ZX = NT2_LOAD(zx + o + ro + c); A2 = NT_LOAD(a2 + o + ro + c); }
+    ZY = RL_LOAD(zy + o + ro + c); ZX = RL_LOAD(zx + o + ro + c); A2 = RL_LOAD(a2 + o + ro + c); }
     LOAD_WIN(1, pc_0, pjm_0, pim_0, pjp_0, pip_0, zy_0, zx_0, a2_0)
     LOAD_WIN(2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
     for (int k = 1; k <= nz; k++) {
@@ -576,22 +604,22 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
       const double a4jp = a4[o + ro + jp], a7ip = a7[op + ro + c];
       double rr;
       if (k == 1) {
-        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
+        rr = RL_LOAD(b + ko) - RL_LOAD(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - RL_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - RL_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zxip + zx_p)) * pip_p;
         if (REAL)
           rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
       } else if (k < nz) {
-        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
-                   - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
-                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
+        rr = RL_LOAD(b + ko) - RL_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
+                   - RL_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
+                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - RL_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
       } else {
-        rr = NT_LOAD(b + ko) - NT_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - NT2_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - NT2_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
+        rr = RL_LOAD(b + ko) - RL_LOAD(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - RL_LOAD(a4 + ko) * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - RL_LOAD(a7 + ko) * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m;
       }
-      NT2_STORE(rr, r + ko);
+      st_rt(r + ko, rr, stream);
       mirror_store(L, r, ro, jodd ? 2 * jh + 1 : 2 * jh + 2, i, c, rr, ph);
       acc = acc + rr * rr;
       pc_m = pc_0; pc_0 = pc_p; pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
@@ -656,7 +684,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
 // `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph) {
+__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph, int stream) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (j2 > C.ny || i2 > C.nx) return;
@@ -667,8 +695,8 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
   const long long oc = (long long)i2 * C.plane + jpos(C, j2);
   for (int k2 = 1; k2 <= C.nz; k2++) {
     const long long r0 = (long long)(2 * k2 - 2) * F.RS, r1 = r0 + F.RS;
-    const double z = x[o0 + r0 + po] + x[o1 + r0 + po] + x[o0 + r0 + pe] + x[o1 + r0 + pe]
-                   + x[o0 + r1 + po] + x[o1 + r1 + po] + x[o0 + r1 + pe] + x[o1 + r1 + pe];
+    const double z = ld_rt(x + o0 + r0 + po, stream) + ld_rt(x + o1 + r0 + po, stream) + ld_rt(x + o0 + r0 + pe, stream) + ld_rt(x + o1 + r0 + pe, stream)
+                   + ld_rt(x + o0 + r1 + po, stream) + ld_rt(x + o1 + r1 + po, stream) + ld_rt(x + o0 + r1 + pe, stream) + ld_rt(x + o1 + r1 + pe, stream);
     dst[oc + (long long)(k2 - 1) * C.RS] = z;
     mirror_store(C, dst, (long long)(k2 - 1) * C.RS, j2, i2, jpos(C, j2), z, ph);
   }
@@ -680,7 +708,7 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
 // One lane = one coarse column = 2x2 fine columns.  `src` is the coarse p (or the split block).
 // ------------------------------------------------------------------------------------------------
 template <bool LINEAR>
-__global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc, Sides ph) {
+__global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc, Sides ph, int stream) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int k2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   const int i2 = 1 + blockIdx.z;
@@ -694,7 +722,7 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
   double *__restrict__ pf = F.p;
   const int nz = C.nz;
 #define XC(kk, JJ, QQ) xc[QQ + (long long)((kk)-1) * C.RS + JJ]
-#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = pf[t_] + v_; rf[t_] = v_; pf[t_] = w_; \
+#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = ld_rt(pf + t_, stream) + v_; st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream); \
     const int jf_ = (PP == po) ? 2 * j2 - 1 : 2 * j2, if_ = (OO == o0) ? i : i + 1; \
     mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
   if (!LINEAR) {
@@ -934,24 +962,28 @@ template <int NZ, int D>
 static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   static const bool noxcd = getenv("MGX_NO_XCD") != nullptr;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE, gx = noxcd ? -gx0 : gx0;
-  static const int by = getenv("MGX_BY") ? atoi(getenv("MGX_BY")) : 2;
+  // two planes per workgroup only when there are plenty of workgroups (it halves the number of CUs a small level uses)
+  const int by = gx0 * nplanes >= 2048 ? 2 : 1;
   dim3 blk(WAVE, by), grd(gx0 * ((nplanes + by - 1) / by));
   const bool mf = L->zy != nullptr && NZ >= 16;  // matrix-free cross terms on the bandwidth-bound levels
-  if (mf) {
-    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-    return;
+  // streaming (nontemporal) hints only when the level cannot live in the 256 MB Infinity Cache between passes:
+  // measured +14 % on the 1.2 GB level 1, -20 % on the 150 MB level 2 which is otherwise re-read from cache
+  const bool stream = mf && (double)L->nx * L->ny * NZ * 72.0 > 256e6;
+#define LAUNCH_NZ(MFV, STV)                                                                                              \
+  {                                                                                                                       \
+    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
+    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
+    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);            \
   }
-  if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-  else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-  else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+  if (mf && stream) LAUNCH_NZ(true, true)
+  else if (mf) LAUNCH_NZ(true, false)
+  else LAUNCH_NZ(false, false)
+#undef LAUNCH_NZ
 }
 template <int NZ>
 static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
-  // look-ahead depth D (rows of loads in flight): 3 for the long columns; the short ones (<= 16 levels) are
-  // latency-bound on few waves and take everything they can hold
-  constexpr int D = NZ >= 32 ? 3 : (NZ >= 8 ? 7 : 1);
+  // look-ahead depth D (rows of loads in flight)
+  constexpr int D = NZ >= 8 ? 3 : 1;  // (a deeper look-ahead was measured slower on the 8- and 16-level grids)
 #ifdef MGX_TUNE_D
   if (NZ == 64) {
     static const int dd = getenv("MGX_D") ? atoi(getenv("MGX_D")) : 3;
@@ -1031,10 +1063,10 @@ void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *ou
   dim3 blk(WAVE, 4), g3 = col_grid(L->ny / 2, L->nx, 2), grd(g3.x * g3.y * 2);
   const int gx = g3.x, gy = g3.y;
   if (L->zy != nullptr && L->nz >= 3) {
-    if (real) hipLaunchKernelGGL((k_residual_mf<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
-    else hipLaunchKernelGGL((k_residual_mf<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
-  } else if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
-  else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph);
+    if (real) hipLaunchKernelGGL((k_residual_mf<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph, level_streams(L));
+    else hipLaunchKernelGGL((k_residual_mf<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph, level_streams(L));
+  } else if (real) hipLaunchKernelGGL((k_residual<true>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph, level_streams(L));
+  else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph, level_streams(L));
   if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)grd.x, out);
 }
 void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *partial, double *out) {
@@ -1043,13 +1075,13 @@ void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *parti
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph) {
-  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph);
+  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F));
 }
 void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph) {
   const int by = C->nz >= 4 ? 4 : C->nz;
   dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
-  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src, ph);
-  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src, ph);
+  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F));
+  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F));
 }
 void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
   const int n = L->nx + L->ny + 1;
