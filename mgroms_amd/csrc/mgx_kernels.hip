@@ -983,13 +983,14 @@ static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int iste
 template <int NZ>
 static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   // look-ahead depth D (rows of loads in flight)
-  constexpr int D = NZ >= 8 ? 3 : 1;  // (a deeper look-ahead was measured slower on the 8- and 16-level grids)
+  constexpr int D = NZ >= 32 ? 3 : (NZ >= 8 ? 2 : 1);  // measured: NZ=16 6.3 us/pass at D=2 vs 9.3 at D=3; NZ>=32 flat for D=2..5
 #ifdef MGX_TUNE_D
-  if (NZ == 64) {
+  if (NZ >= 8) {
     static const int dd = getenv("MGX_D") ? atoi(getenv("MGX_D")) : 3;
+    if (dd == 1) return launch_relax_nz_d<NZ, 1>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
     if (dd == 2) return launch_relax_nz_d<NZ, 2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
-    if (dd == 4) return launch_relax_nz_d<NZ, 4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
     if (dd == 5) return launch_relax_nz_d<NZ, 5>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
+    if (dd == 7) return launch_relax_nz_d<NZ, 7>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
   }
 #endif
   launch_relax_nz_d<NZ, D>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph);
