@@ -168,7 +168,7 @@ def main():
 
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true>"
+    kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>"
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
