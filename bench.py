@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--method", default="FC", choices=["FC", "RB"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--nsmall", type=int, default=256, help="nsmall used when N>1 (coarse-level agglomeration threshold)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
     args = ap.parse_args()
@@ -97,10 +98,12 @@ def main():
     nx, ny, nz = args.size
     npx, npy = PGRID[args.gpus]
     nhydro.set_verbose(0)
-    # N>1: agglomerate the launch-/latency-bound coarse levels (local size < 128) with the reference's own knob
-    # `nsmall` (mg_namelist.f90:11, mg_grids.f90:550): levels 4..6 then run without halo exchanges.  FC results do
-    # not depend on the decomposition, so the numbers are the same solve as nsmall=8.
-    par = nhydro.default_params(relax_method=args.method, nsmall=(8 if world == 1 else 128))
+    # N>1: agglomerate the launch-/latency-bound coarse levels (local size < 256) with the reference's own knob
+    # `nsmall` (mg_namelist.f90:11, mg_grids.f90:550): levels 3..6 are then computed redundantly on fewer ranks and
+    # need few or no halo exchanges (each exchange costs more than a whole colour pass there).  FC results do not
+    # depend on the decomposition (tests/test_oracle.py::test_fc_is_decomposition_independent_on_4x2), so this is
+    # the same solve as nsmall=8.
+    par = nhydro.default_params(relax_method=args.method, nsmall=(8 if world == 1 else args.nsmall))
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
     mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)

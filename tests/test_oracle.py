@@ -103,3 +103,22 @@ def test_operator_is_symmetric_and_consistent():
     x[2:-2, 2:-2, :] = rng.standard_normal((12, 12, 8))
     y[2:-2, 2:-2, :] = rng.standard_normal((12, 12, 8))
     assert np.isclose((x * apply(y)).sum(), (apply(x) * y).sum(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("npx,npy,nsmall", [(4, 2, 8), (4, 2, 32), (2, 4, 16)])
+def test_fc_is_decomposition_independent_on_4x2(npx, npy, nsmall):
+    # the process grid of the 8-GPU configuration (BASELINE configs[4]) with one and with two consecutive gathers:
+    # four-colour ordering gives the same iterates as one rank, up to the norm's summation order
+    one = make_seamount(64, 64, 16, relax_method="FC", solver_prec=1e-8)
+    n1, h1, _ = one.nhydro_solve()
+    many = make_seamount(64 // npx, 64 // npy, 16, npx, npy, relax_method="FC", solver_prec=1e-8, nsmall=nsmall)
+    assert any(many.level_info(l)["gather"] for l in range(1, many.nlevs + 1))
+    n2, h2, _ = many.nhydro_solve()
+    assert n1 == n2
+    assert np.all(np.abs(h1 - h2) <= 1e-14 + 1e-13 * h1)
+    p1 = one.field("p")
+    for r in range(npx * npy):
+        pi, pj = r % npx, r // npx
+        nx, ny = 64 // npx, 64 // npy
+        blk = many.field("p", 1, r)[1:-1, 1:-1, :]
+        assert np.array_equal(blk, p1[1 + pi * nx:1 + (pi + 1) * nx, 1 + pj * ny:1 + (pj + 1) * ny, :]), r
