@@ -405,8 +405,8 @@ __global__ __launch_bounds__(64, 1) void k_relax_gs_front(LevView L, int t) {
 // workgroup: colours are separated by __syncthreads() instead of kernel boundaries.  The coarsest-level solve of
 // the reference (40 sweeps, mg_solvers.f90:117,144) is 160 colour passes of a 16x16x2 grid: launch-bound as
 // separate kernels, ~1 us per pass here.  method: 1 = RB, 2 = FC.
-template <int NZ, bool REAL>
-__global__ __launch_bounds__(256) void k_relax_small(LevView L, int nsweeps, int method, Sides ph) {
+template <int NZ, bool REAL, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_relax_small(LevView L, int nsweeps, int method, Sides ph) {
   const int tid = threadIdx.x, nth = blockDim.x;
   const int nyh = L.ny >> 1;
   for (int it = 0; it < nsweeps; it++) {
@@ -999,11 +999,18 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
   }
   const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
   // one CU streams ~25-50 GB/s: worth it only while the level is launch-bound, not bandwidth-bound (measured:
-  // 16x16x2 and 32x32x4 win, 64x64x8 loses 2x against separate launches over 256 CUs)
-  if (ncol > 256 || L->nz > 8 || !(ph.S && ph.E && ph.N && ph.W)) return 0;
+  // 16x16x2 and 32x32x4 win, 64x64x8 loses 2x against separate launches over 256 CUs).  A 2-level-deep coarsest grid
+  // is still launch-bound at 1024 columns per colour (the gathered 64x32x2 grid of an 8-GPU run): 1024 threads.
+  if (!(ph.S && ph.E && ph.N && ph.W)) return 0;
+  if (L->nz == 2 && ncol > 256 && ncol <= 1024) {
+    if (real) hipLaunchKernelGGL((k_relax_small<2, true, 1024>), dim3(1), dim3(1024), 0, st, *L, nsweeps, method, ph);
+    else hipLaunchKernelGGL((k_relax_small<2, false, 1024>), dim3(1), dim3(1024), 0, st, *L, nsweeps, method, ph);
+    return 1;
+  }
+  if (ncol > 256 || L->nz > 8) return 0;
   const int nth = ncol <= 64 ? 64 : 256;
-#define SMALL_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_small<NZV, true>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); \
-                                  else hipLaunchKernelGGL((k_relax_small<NZV, false>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); return 1;
+#define SMALL_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_small<NZV, true, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); \
+                                  else hipLaunchKernelGGL((k_relax_small<NZV, false, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph); return 1;
   switch (L->nz) { SMALL_CASE(2) SMALL_CASE(4) SMALL_CASE(8) default: return 0; }
 #undef SMALL_CASE
 }

@@ -211,7 +211,8 @@ def test_16x16x8_reference_scalars(mg, golden):
 
 def test_ragged_and_minimum_sizes(mg):
     # smallest hierarchy the reference accepts (one level) and a non-square block
-    for dims in ((4, 4, 2), (8, 16, 4), (128, 32, 8)):
+    # (256,128,8): coarsest level 64x32x2 = the gathered coarsest grid of an 8-GPU run (one 1024-thread launch)
+    for dims in ((4, 4, 2), (8, 16, 4), (128, 32, 8), (256, 128, 8)):
         o = _setup(mg, *dims)
         u, v, w = _uvw(*dims)
         mg.nhydro.compute_rhs(u, v, w)
