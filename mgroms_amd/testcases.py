@@ -20,12 +20,12 @@ def seamount_geometry(nx, ny, npx=1, npy=1, rank=0, Lx=1e4, Ly=1e4, Htot=4e3):
 
 
 def rndtopo_geometry(nx, ny, npx=1, npy=1, rank=0, Lx=1e4, Ly=1e4, Htot=4e3, seed=12345):
-    """Decomposition-independent random topography (BASELINE config 4): h = Htot*(1 - 0.2*U), one draw per GLOBAL
+    """Decomposition-independent random topography (BASELINE config 4): h = Htot*0.2*U ("between 0% and 20% of Htot", mg_setup_tests.f90:199), one draw per GLOBAL
     (i,j) from a seeded generator, mirrored into the physical halo, then cut to this rank's block."""
     nxg, nyg = npx * nx, npy * ny
     pj, pi = rank // npx, rank % npx
     rng = np.random.Generator(np.random.PCG64(seed))
-    hg = np.pad(Htot * (1.0 - 0.2 * rng.random((nxg, nyg))), 1, mode="edge")
+    hg = np.pad(Htot * 0.2 * rng.random((nxg, nyg)), 1, mode="edge")
     h = hg[pi * nx:pi * nx + nx + 2, pj * ny:pj * ny + ny + 2].copy()
     return (np.full((nx + 2, ny + 2), Lx / float(nxg)), np.full((nx + 2, ny + 2), Ly / float(nyg)),
             np.zeros((nx + 2, ny + 2)), h)

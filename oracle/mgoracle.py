@@ -177,13 +177,12 @@ def seamount_geometry(nx, ny, npx, npy, rank, Lx=1e4, Ly=1e4, Htot=4e3):
 
 
 def rndtopo_geometry(nx, ny, npx, npy, rank, Lx=1e4, Ly=1e4, Htot=4e3, seed=12345):
-    """Decomposition-independent random topography: h = Htot*(1-0.2*U) drawn once per
+    """Decomposition-independent random topography: h = Htot*0.2*U ("between 0% and 20% of Htot", mg_setup_tests.f90:199) drawn once per
     GLOBAL (i,j) from a seeded generator owned by this build, mirrored into the physical halo."""
     nxg, nyg = npx * nx, npy * ny
     pj, pi = rank // npx, rank % npx
     rng = np.random.Generator(np.random.PCG64(seed))
-    hg = Htot * (1.0 - 0.2 * rng.random((nxg, nyg)))
-    hg = np.pad(hg, 1, mode="edge")
+    hg = np.pad(Htot * 0.2 * rng.random((nxg, nyg)), 1, mode="edge")
     h = hg[pi * nx:pi * nx + nx + 2, pj * ny:pj * ny + ny + 2].copy()
     dx = np.full((nx + 2, ny + 2), Lx / float(nxg))
     dy = np.full((nx + 2, ny + 2), Ly / float(nyg))
