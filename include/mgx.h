@@ -41,12 +41,12 @@ typedef struct mgx_params {
   char restrict_type[16]; /* 'avg' (never read by the reference outside the namelist) */
   int aggressive;         /* .false. ; .true. is rejected (unimplemented in the reference, mg_intergrids.f90:243) */
   int netcdf_output;      /* .false. ; ignored (debug I/O, out of scope) */
-  int bmask;              /* .false. ; .true. is rejected this round */
+  int bmask;              /* .false. ; .true. = masked coefficients, needs rmask in mgx_matrices */
 } mgx_params;
 
 /* field ids for mgx_get_field / mgx_set_field / mgx_fill_halo */
 enum { MGX_P = 0, MGX_B = 1, MGX_R = 2, MGX_CA = 3, MGX_DX = 4, MGX_DY = 5, MGX_ZETA = 6, MGX_H = 7,
-       MGX_ZR = 8, MGX_ZW = 9, MGX_CW = 10 };
+       MGX_ZR = 8, MGX_ZW = 9, MGX_CW = 10, MGX_RMASK = 14 };
 
 /* fills *p with the defaults of mg_namelist.f90:11-35 */
 int mgx_params_default(mgx_params *p);

@@ -22,7 +22,7 @@
 #include "mgx_internal.h"
 
 struct RectOp { int op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, mi2, ci2; };
-struct ModelView { double *u, *v, *w, *rmask; };
+struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 
 extern "C" {
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
@@ -45,7 +45,7 @@ void mgxk_split(hipStream_t, const LevView *, const LevView *, const double *, d
 void mgxs_coarsen2d(hipStream_t, const double *, double *, int, int, int, double);
 void mgxs_rect(hipStream_t, double *, double *, const RectOp *);
 void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
-void mgxs_define_matrix(hipStream_t, const GeoView *, int);
+void mgxs_define_matrix(hipStream_t, const GeoView *, int lev1, int phase);
 void mgxs_pivots(hipStream_t, const LevView *);
 void mgxs_slopes_js(hipStream_t, const GeoView *, const LevView *);
 void mgxs_rhs_uf(hipStream_t, const GeoView *, const ModelView *, double *);
@@ -228,11 +228,14 @@ void rect(double *a, double *buf, int op, int nzz, int nh, int ny, int j0, int j
   S.n_launch++;
 }
 
-int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c) {
+// xonly = fill_halo_4D (mg_mpi_exchange.f90:1245-1552): only the exchange with existing neighbours
+int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c, bool xonly = false) {
   S.n_halo++;
   const int nx = L.nx, ny = L.ny;
   const int *nb = L.neighb;
   const int So = nb[0], E = nb[1], N = nb[2], W = nb[3], SW = nb[4], SE = nb[5], NE = nb[6], NW = nb[7];
+  const bool zSW = (c == 'u' && W < 0), zSE = (c == 'u' && E < 0), zNE = (c == 'u' && E < 0) || c == 'v', zNW = (c == 'u' && W < 0) || c == 'v';
+  if (!xonly) {
   // phase 1: physical sides, in the reference's order S,E,N,W then the corners
   if (So < 0) {
     if (c == 'v') rect(a, 0, 2, nzz, nh, ny, 1, 1, 1 - nh, nx + nh);
@@ -250,11 +253,11 @@ int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c) {
     if (c == 'u') rect(a, 0, 2, nzz, nh, ny, 1 - nh, ny + nh, 1, 1);
     else { rect(a, 0, 0, nzz, nh, ny, 1, ny, 0, 0, 0, 0, 0, 1); if (nh == 2) rect(a, 0, 1, nzz, nh, ny, 1, ny, -1, -1, 0, 0, 0, 2, 0, 0, 0, 3); }
   }
-  const bool zSW = (c == 'u' && W < 0), zSE = (c == 'u' && E < 0), zNE = (c == 'u' && E < 0) || c == 'v', zNW = (c == 'u' && W < 0) || c == 'v';
   if (SW < 0) { if (zSW) rect(a, 0, 2, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0); else if (So < 0 && W < 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 1, 1, 1, 1); }
   if (SE < 0) { if (zSE) rect(a, 0, 2, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh); else if (So < 0 && E < 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 1, 1, 1, 2 * nx + 1); }
   if (NE < 0) { if (zNE) rect(a, 0, 2, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh); else if (N < 0 && E < 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, nx + 1, nx + nh, 1, 2 * ny + 1, 1, 2 * nx + 1); }
   if (NW < 0) { if (zNW) rect(a, 0, 2, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0); else if (N < 0 && W < 0) rect(a, 0, 0, nzz, nh, ny, ny + 1, ny + nh, 1 - nh, 0, 1, 2 * ny + 1, 1, 1); }
+  }
   // phase 2: exchange with the existing neighbours
   int n = 0, peer[8], cnt[8];
   double *sb[8], *rb[8];
@@ -276,6 +279,7 @@ int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c) {
     CHK(exchange(n, peer, sb, rb, cnt));
     for (int q = 0; q < n; q++) rect(a, rb[q], 4, nzz, nh, ny, rr[q][0], rr[q][1], rr[q][2], rr[q][3]);
   }
+  if (xonly) return 0;
   // phase 3: mixed corners (:1216-1240)
   if (SW < 0 && !zSW) { if (So >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 0, 0, 1, 1); else if (W >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, 1 - nh, 0, 1, 1, 0, 0); }
   if (SE < 0 && !zSE) { if (So >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 0, 0, 1, 2 * nx + 1); else if (E >= 0) rect(a, 0, 0, nzz, nh, ny, 1 - nh, 0, nx + 1, nx + nh, 1, 1, 0, 0); }
@@ -542,29 +546,44 @@ int define_matrices() {
     CHK(rl_fill_halo(L, L.g.zr, L.nz, 2, 0));
     CHK(rl_fill_halo(L, L.g.zw, L.nz + 1, 2, 0));
     HIPCHK(hipMemsetAsync(L.g.cA, 0, (size_t)8 * L.nz * (L.ny + 2) * (L.nx + 2) * sizeof(double), S.stream));
-    mgxs_define_matrix(S.stream, &L.g, l == 0); S.n_launch += 3;
+    L.g.bmask = S.par.bmask ? 1 : 0;
+    if (l > 0) {  // boundary mask of a coarse level = 1, 0 in the physical halo when bmask (:157-161, fill_halo_2D_bmask)
+      rect(L.g.rmask, 0, 5, 1, 1, L.ny, 0, L.ny + 1, 0, L.nx + 1);
+      if (S.par.bmask) {
+        if (L.neighb[0] < 0) rect(L.g.rmask, 0, 2, 1, 1, L.ny, 0, 0, 0, L.nx + 1);
+        if (L.neighb[1] < 0) rect(L.g.rmask, 0, 2, 1, 1, L.ny, 0, L.ny + 1, L.nx + 1, L.nx + 1);
+        if (L.neighb[2] < 0) rect(L.g.rmask, 0, 2, 1, 1, L.ny, L.ny + 1, L.ny + 1, 0, L.nx + 1);
+        if (L.neighb[3] < 0) rect(L.g.rmask, 0, 2, 1, 1, L.ny, 0, L.ny + 1, 0, 0);
+      }
+    }
+    mgxs_define_matrix(S.stream, &L.g, l == 0, 0); S.n_launch += 2;
+    if (S.par.bmask) CHK(rl_fill_halo(L, L.g.cA, 8 * L.nz, 1, 0, true));  // fill_halo(lev,cA), mg_define_matrix.f90:611-613
+    mgxs_define_matrix(S.stream, &L.g, l == 0, 1); S.n_launch++;
     for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
-    if (S.no_mf) L.v.zy = L.v.zx = nullptr;
+    if (S.no_mf || S.par.bmask) L.v.zy = L.v.zx = nullptr;  // masked coefficients are not rebuilt from the slopes
   }
   HIPCHK(hipStreamSynchronize(S.stream));
   S.have_matrix = true;
   return 0;
 }
 
+// the model fields + the level-1 mask (only read when bmask)
+ModelView model_view() { return ModelView{S.d_u, S.d_v, S.d_w, S.par.bmask ? S.lev[0].g.rmask : nullptr, S.par.bmask ? 1 : 0}; }
+
 // mg_compute_rhs.f90:14-379 on the device copies of u,v,w
 int compute_rhs_dev() {
   Level &L = S.lev[0];
   TicScope ts(1, "compute_rhs");  // nhydro.f90:81
-  ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+  ModelView M = model_view();
   HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));
   mgxs_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'u'));
+  if (!S.par.bmask) CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'u'));  // mg_compute_rhs.f90:170-172
   mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 0); S.n_launch++;
   mgxs_rhs_vf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'v'));
+  if (!S.par.bmask) CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'v'));  // :271-273
   mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 1); S.n_launch++;
   mgxs_rhs_wf(S.stream, &L.g, &M, S.d_fz); S.n_launch++;
   mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fz, 2); S.n_launch++;
@@ -591,7 +610,6 @@ int apply_params(const mgx_params &p) {
   if (streq(p.interp_type, "linear")) S.linear = 1; else if (streq(p.interp_type, "nearest")) S.linear = 0; else return fail("unknown interp_type '%s'", p.interp_type);
   if (S.linear && streq(p.restrict_type, "linear")) return fail("linear interp + linear restrict is not permitted");
   if (p.aggressive) return fail("aggressive=.true.: coarse2fine_aggressive is not available in the reference either (mg_intergrids.f90:243)");
-  if (p.bmask) return fail("bmask=.true. is not supported by this build (SURVEY 8 row f3)");
   S.par = p;
   return 0;
 }
@@ -724,6 +742,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
     CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));
+    CHK(dmalloc(&L.g.rmask, n2)); L.g.bmask = 0;
     CHK(dmalloc(&L.g.zr, (size_t)(L.ny + 4) * (L.nx + 4) * L.nz));
     CHK(dmalloc(&L.g.zw, (size_t)(L.ny + 4) * (L.nx + 4) * (L.nz + 1)));
     CHK(dmalloc(&L.g.cw, n2 * (L.nz + 1)));
@@ -751,6 +770,10 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.ref_scratch, S.ref_scratch_n));
   for (auto &L : S.lev) L.g.cA = S.ref_scratch;
   S.xbuf_n = (size_t)(L1.nz + 1) * 2 * ((L1.nx > L1.ny ? L1.nx : L1.ny) + 4);
+  if (S.par.bmask && S.nranks > 1) {  // the 4-D cA halo of define_matrix travels through the same buffers
+    const size_t n4 = (size_t)8 * L1.nz * (L1.nx > L1.ny ? L1.nx : L1.ny);
+    if (n4 > S.xbuf_n) S.xbuf_n = n4;
+  }
   for (int q = 0; q < 16; q++) CHK(dmalloc(&S.xbuf[q], S.xbuf_n));
   CHK(dmalloc(&S.d_u, (size_t)(L1.nx + 1) * (L1.ny + 2) * L1.nz));
   CHK(dmalloc(&S.d_v, (size_t)(L1.nx + 2) * (L1.ny + 1) * L1.nz));
@@ -781,7 +804,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
 int mgx_matrices(const double *dx, const double *dy, const double *zeta, const double *h, const double *rmask, double hc,
                  double theta_b, double theta_s) {
   NEED_INIT();
-  (void)rmask;  // only read when bmask=.true., which mgx_init rejects
+  if (S.par.bmask && !rmask) return fail("bmask=.true. needs rmask in mgx_matrices (nhydro.f90:52-55)");
   if (S.verbose && S.rank == 0) printf("  nhydro_matrices:\n");
   S.hlim = hc; S.theta_b = theta_b; S.theta_s = theta_s;
   Level &L = S.lev[0];
@@ -790,12 +813,13 @@ int mgx_matrices(const double *dx, const double *dy, const double *zeta, const d
   HIPCHK(hipMemcpyAsync(L.g.dy, dy, n2, hipMemcpyHostToDevice, S.stream));
   HIPCHK(hipMemcpyAsync(L.g.zeta, zeta, n2, hipMemcpyHostToDevice, S.stream));
   HIPCHK(hipMemcpyAsync(L.g.h, h, n2, hipMemcpyHostToDevice, S.stream));
+  if (S.par.bmask) HIPCHK(hipMemcpyAsync(L.g.rmask, rmask, n2, hipMemcpyHostToDevice, S.stream));  // grid(1)%rmask = rmask
   return define_matrices();
 }
 
 int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask) {
   NEED_INIT();
-  (void)rmask;
+  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before compute_rhs");
   CHK(upload_uvw(u, v, w));
   CHK(compute_rhs_dev());
@@ -805,14 +829,14 @@ int mgx_compute_rhs(const double *u, const double *v, const double *w, const dou
 
 int mgx_solve(double *u, double *v, double *w, const double *rmask) {
   NEED_INIT();
-  (void)rmask;
+  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve");
   if (S.verbose && S.rank == 0) printf("  nhydro_solve:\n");
   CHK(upload_uvw(u, v, w));
   CHK(compute_rhs_dev());
   CHK(solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr));
   Level &L = S.lev[0];
-  ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+  ModelView M = model_view();
   mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
   const size_t nu = (size_t)(L.nx + 1) * (L.ny + 2) * L.nz, nv = (size_t)(L.nx + 2) * (L.ny + 1) * L.nz, nw = (size_t)(L.nx + 2) * (L.ny + 2) * (L.nz + 1);
   HIPCHK(hipMemcpyAsync(u, S.d_u, nu * sizeof(double), hipMemcpyDeviceToHost, S.stream));
@@ -826,7 +850,7 @@ int mgx_solve(double *u, double *v, double *w, const double *rmask) {
 // (e.g. torch tensors); nothing crosses PCIe.  The library's own staging copies are bypassed.
 int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *rmask) {
   NEED_INIT();
-  (void)rmask;
+  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve_device");
   double *su = S.d_u, *sv = S.d_v, *sw = S.d_w;
   S.d_u = u_dev; S.d_v = v_dev; S.d_w = w_dev;
@@ -834,7 +858,7 @@ int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *
   if (!rc) rc = solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr);
   if (!rc) {
     Level &L = S.lev[0];
-    ModelView M = {S.d_u, S.d_v, S.d_w, nullptr};
+    ModelView M = model_view();
     mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
     if (hipStreamSynchronize(S.stream) != hipSuccess) rc = fail("stream synchronize failed");
   }
@@ -934,6 +958,7 @@ static int field_ptr(Level &L, int field, double **a, size_t *n) {
     case MGX_ZR: *a = L.g.zr; *n = (size_t)(L.ny + 4) * (L.nx + 4) * L.nz; return 0;
     case MGX_ZW: *a = L.g.zw; *n = (size_t)(L.ny + 4) * (L.nx + 4) * (L.nz + 1); return 0;
     case MGX_CW: *a = L.g.cw; *n = n2 * (L.nz + 1); return 0;
+    case MGX_RMASK: *a = L.g.rmask; *n = n2; return 0;
   }
   return 1;
 }

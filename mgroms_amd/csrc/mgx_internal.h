@@ -31,6 +31,8 @@ struct GeoView {
   double *cw;                  // (nz+1, 0:ny+1, 0:nx+1)
   double *cA;                  // (8, nz, 0:ny+1, 0:nx+1)   scratch shared by all levels
   double *dzw, *zxdy, *zydx;   // level 1 only
+  double *rmask;               // (0:ny+1, 0:nx+1) boundary / land mask of the level (mg_define_matrix.f90:78-79,157-161)
+  int bmask;                   // namelist bmask: masked coefficients
 };
 
 // physical-boundary flags of a sub-domain (1 = no neighbour on that side)

@@ -15,6 +15,11 @@
 #define CW(k, j, i) G.cw[I3P(k, j, i)]
 #define CA(s, k, j, i) G.cA[I3(k, j, i) * 8 + ((s)-1)]
 
+// umask(j,i) = rmask(j,i-1)*rmask(j,i) for i>=1, vmask(j,i) = rmask(j-1,i)*rmask(j,i) for j>=1, 0 elsewhere; all 1 without bmask
+#define RMK(j, i) A2(G.rmask, j, i)
+#define UM(j, i) (G.bmask ? (((i) >= 1) ? RMK(j, (i)-1) * RMK(j, i) : 0.0) : 1.0)
+#define VM(j, i) (G.bmask ? (((j) >= 1) ? RMK((j)-1, i) * RMK(j, i) : 0.0) : 1.0)
+
 #define COLUMN_THREAD(jlo, jhi, ilo, ihi)                                     \
   const int j = (jlo) + blockIdx.x * blockDim.x + threadIdx.x;                \
   const int i = (ilo) + blockIdx.y * blockDim.y + threadIdx.y;                \
@@ -47,6 +52,7 @@ __global__ void k_rect(double *__restrict__ a, double *__restrict__ buf, RectOp 
 #define AI(jj, ii) (((long long)((ii) + R.nh - 1)) * sj + ((jj) + R.nh - 1)) * R.nzz + k
   const long long d = AI(j, i);
   if (R.op == 2) { a[d] = 0.0; return; }
+  if (R.op == 5) { a[d] = 1.0; return; }
   if (R.op == 3) { buf[t] = a[d]; return; }
   if (R.op == 4) { a[d] = buf[t]; return; }
   const int sjj = R.mj ? R.cj - j : j + R.cj, sii = R.mi ? R.ci - i : i + R.ci;
@@ -116,7 +122,7 @@ __global__ void k_cA_offdiag(GeoView G) {
   int k = 1;
   if (in345) {
     CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
-                            (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+                            (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
     const double t1 = ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
     const double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i));
     CA(4, k, j, i) =
@@ -125,10 +131,18 @@ __global__ void k_cA_offdiag(GeoView G) {
         - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)))
         - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i) -
                  (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+    if (G.bmask)  // :375-389
+      CA(4, k, j, i) = (CA(4, k, j, i)
+          - (hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
+                 ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
+                 (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * (UM(j - 1, i + 1) - UM(j - 1, i))
+             - hlf * ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DY(j, i)) * DX(j, i)) *
+                   ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) /
+                   (CW(k, j, i) + CW(k + 1, j, i)) * (UM(j, i + 1) - UM(j, i)))) * VM(j, i);
   }
   if (in678) {
     CA(6, k, j, i) = qrt * ((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i) +
-                            (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * one;
+                            (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * UM(j, i);
     const double t1 = ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
     const double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1));
     CA(7, k, j, i) =
@@ -137,42 +151,58 @@ __global__ void k_cA_offdiag(GeoView G) {
         - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)))
         - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1) -
                  (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+    if (G.bmask)  // :417-433
+      CA(7, k, j, i) = (CA(7, k, j, i)
+          - (hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                 ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                 (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * (VM(j + 1, i - 1) - VM(j, i - 1))
+             - hlf * ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DY(j, i)) * DX(j, i)) *
+                   ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) /
+                   (CW(k, j, i) + CW(k + 1, j, i)) * (VM(j + 1, i) - VM(j, i)))) * UM(j, i);
   }
   if (j <= ny) {
     CA(5, k, j, i) =
         +hlf * ((hlf * (ZR(k, j + 1, i + 1) - ZR(k, j + 1, i - 1)) / DX(j + 1, i)) * DY(j + 1, i)) *
                 ((hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)) /
-                (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * one * one
+                (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * UM(j + 1, i) * VM(j + 1, i)
         + hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
                 ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
-                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * UM(j, i) * VM(j + 1, i - 1);
   }
   if (j >= 1) {
     CA(8, k, j, i) =
         -hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
                 ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
-                (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * one * one
+                (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * UM(j - 1, i) * VM(j, i)
         - hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
                 ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
-                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+                (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * UM(j, i) * VM(j, i - 1);
   }
   for (k = 2; k <= nz - 1; k++) {
-    if (in345 && j <= ny) CA(2, k, j, i) = CW(k, j, i);
+    if (in345 && j <= ny) {
+      CA(2, k, j, i) = CW(k, j, i);
+      if (G.bmask)  // :497-509
+        CA(2, k, j, i) = CA(2, k, j, i)
+            - qrt * ((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i) -
+                     (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)) * (UM(j, i + 1) - UM(j, i))
+            - qrt * ((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i) -
+                     (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) * (VM(j + 1, i) - VM(j, i));
+    }
     if (in345) {
       CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
-                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
       CA(4, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) *
-                        (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * one;
+                        (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * VM(j, i);
       CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * VM(j, i);
     }
     if (in678) {
       CA(6, k, j, i) = qrt * (((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                              ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                              ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
       CA(7, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) *
-                        (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * one;
+                        (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * UM(j, i);
       CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
     }
   }
   k = nz;
@@ -182,18 +212,18 @@ __global__ void k_cA_offdiag(GeoView G) {
         (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) /
              (hlf * (DY(j, i) + DY(j - 1, i)))
          + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))
-                  + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * one;
+                  + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * VM(j, i);
     CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
-                             ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+                             ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * VM(j, i);
   }
   if (in678) {
     CA(7, k, j, i) =
         (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) /
              (hlf * (DX(j, i) + DX(j, i - 1)))
          + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))
-                  + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * one;
+                  + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * UM(j, i);
     CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                             ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                             ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
   }
 }
 
@@ -255,11 +285,13 @@ __global__ void k_pivots(LevView L) {
 // compute_rhs (mg_compute_rhs.f90:14-379, bmask = .false.) on level 1.  u,v,w are the model's
 // (i,j,k)-ordered arrays on the device; uf/vf share `fx` (nz,0:ny+1,0:nx+1), wf is `fz` (nz+1,..).
 // ------------------------------------------------------------------------------------------------
-struct ModelView { double *u, *v, *w, *rmask; };
+struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 #define U(i, j, k) M.u[(((long long)((k)-1)) * (ny + 2) + (j)) * (nx + 1) + ((i)-1)]
 #define V(i, j, k) M.v[(((long long)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
 #define Wv(i, j, k) M.w[(((long long)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
 #define RM(j, i) (M.rmask ? A2(M.rmask, j, i) : 1.0)
+#define UMK(j, i) (M.bmask ? (((i) >= 1) ? RM(j, (i)-1) * RM(j, i) : 0.0) : 1.0)
+#define VMK(j, i) (M.bmask ? (((j) >= 1) ? RM((j)-1, i) * RM(j, i) : 0.0) : 1.0)
 #define DZW(k, j, i) G.dzw[I3P(k, j, i)]
 #define ZXDY(k, j, i) G.zxdy[I3(k, j, i)]
 #define ZYDX(k, j, i) G.zydx[I3(k, j, i)]
@@ -276,24 +308,24 @@ __global__ void k_rhs_uf(GeoView G, ModelView M, double *__restrict__ fx) {
           ZXDY(k, j, i - 1) * ZXDY(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1))) *
              (hlf * (DX(j, i) + DX(j, i - 1))) * U(i, j, k)
        - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-              (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0) +
+              (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i)) +
           ZXDY(k, j, i - 1) * ZYDX(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * hlf *
-              (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * 1.0 +
-               hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * 1.0))) * 1.0;
+              (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * VMK(j, i - 1) +
+               hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * VMK(j + 1, i - 1)))) * UMK(j, i);
   for (k = 2; k <= nz - 1; k++)
     fx[I3(k, j, i)] =
         (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
          - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                   ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                   ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                  ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+                  ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
   k = nz;
   fx[I3(k, j, i)] =
       (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
        - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                 ZXDY(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                 ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+                ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
 }
 
 __global__ void k_rhs_vf(GeoView G, ModelView M, double *__restrict__ fx) {
@@ -308,24 +340,24 @@ __global__ void k_rhs_vf(GeoView G, ModelView M, double *__restrict__ fx) {
           ZYDX(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i))) *
              hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k)
        - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-              (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0) +
+              (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1)) +
           ZXDY(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * hlf *
-              (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * 1.0 +
-               hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * 1.0))) * 1.0;
+              (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * UMK(j - 1, i) +
+               hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * UMK(j - 1, i + 1)))) * VMK(j, i);
   for (k = 2; k <= nz - 1; k++)
     fx[I3(k, j, i)] =
         (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
          - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                   ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                   ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                  ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+                  ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
   k = nz;
   fx[I3(k, j, i)] =
       (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
        - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                 ZYDX(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                 ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+                ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
 }
 
 __global__ void k_rhs_wf(GeoView G, ModelView M, double *__restrict__ fz) {
@@ -334,22 +366,22 @@ __global__ void k_rhs_wf(GeoView G, ModelView M, double *__restrict__ fz) {
   fz[I3P(1, j, i)] = 0.0;
   for (int k = 2; k <= nz; k++) {
     double t = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-               qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 +
-                            ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0 +
-                            ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
-                            ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0);
-    t = t - qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 +
-                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0 +
-                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
-                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+               qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) +
+                            ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1) +
+                            ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
+                            ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1));
+    t = t - qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) +
+                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i) +
+                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
+                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
     fz[I3P(k, j, i)] = t;
   }
   const int k = nz + 1;
   fz[I3P(k, j, i)] = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-                     hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
-                                  ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0) -
-                     hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
-                                  ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+                     hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
+                                  ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1)) -
+                     hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
+                                  ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
 }
 
 // rhs accumulation into the JS field b of level 1: mode 0: b = fx(i+1)-fx(i) ; 1: b += fx(j+1)-fx(j) ; 2: b += fz(k+1)-fz(k)
@@ -372,11 +404,11 @@ __global__ void k_correct_uvw(GeoView G, LevView L, ModelView M) {
 #define PJS(k, jj, ii) p[(long long)(ii)*L.plane + (long long)((k)-1) * L.RS + jpos(L, jj)]
   if (i >= 1) {
     const double dxu = hlf * (DX(j, i) + DX(j, i - 1));
-    for (int k = 1; k <= nz; k++) U(i, j, k) = U(i, j, k) - one / dxu * (PJS(k, j, i) - PJS(k, j, i - 1)) * 1.0;
+    for (int k = 1; k <= nz; k++) U(i, j, k) = U(i, j, k) - one / dxu * (PJS(k, j, i) - PJS(k, j, i - 1)) * UMK(j, i);
   }
   if (j >= 1) {
     const double dyv = hlf * (DY(j, i) + DY(j - 1, i));
-    for (int k = 1; k <= nz; k++) V(i, j, k) = V(i, j, k) - one / dyv * (PJS(k, j, i) - PJS(k, j - 1, i)) * 1.0;
+    for (int k = 1; k <= nz; k++) V(i, j, k) = V(i, j, k) - one / dyv * (PJS(k, j, i) - PJS(k, j - 1, i)) * VMK(j, i);
   }
   for (int k = 2; k <= nz; k++) {
     const double dzw = ZR(k, j, i) - ZR(k - 1, j, i);
@@ -404,10 +436,13 @@ void mgxs_rect(hipStream_t st, double *a, double *buf, const RectOp *R) {
 void mgxs_zr_zw(hipStream_t st, const GeoView *G, double hlim, double theta_b, double theta_s) {
   hipLaunchKernelGGL(k_zr_zw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, hlim, theta_b, theta_s);
 }
-void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1) {
-  hipLaunchKernelGGL(k_cw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, lev1);
-  hipLaunchKernelGGL(k_cA_offdiag, cgrid(G->ny + 2, G->nx + 1), CBLK, 0, st, *G);
-  hipLaunchKernelGGL(k_cA_diag, cgrid(G->ny, G->nx), CBLK, 0, st, *G);
+void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
+  if (phase == 0) {
+    hipLaunchKernelGGL(k_cw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, lev1);
+    hipLaunchKernelGGL(k_cA_offdiag, cgrid(G->ny + 2, G->nx + 1), CBLK, 0, st, *G);
+  } else {
+    hipLaunchKernelGGL(k_cA_diag, cgrid(G->ny, G->nx), CBLK, 0, st, *G);
+  }
 }
 void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }

@@ -9,7 +9,7 @@ import numpy as np
 
 from ._lib import Params, MgxError, lib, check  # noqa: F401
 
-FIELD = {"p": 0, "b": 1, "r": 2, "cA": 3, "dx": 4, "dy": 5, "zeta": 6, "h": 7, "zr": 8, "zw": 9, "cw": 10}
+FIELD = {"p": 0, "b": 1, "r": 2, "cA": 3, "dx": 4, "dy": 5, "zeta": 6, "h": 7, "zr": 8, "zw": 9, "cw": 10, "rmask": 14}
 _DP = C.POINTER(C.c_double)
 _state = {"dims": None}
 
@@ -181,7 +181,7 @@ class _Level:
         nx, ny, nz = self.nx, self.ny, self.nz
         return {"p": (nx + 2, ny + 2, nz), "b": (nx + 2, ny + 2, nz), "r": (nx + 2, ny + 2, nz),
                 "cA": (nx + 2, ny + 2, nz, 8), "dx": (nx + 2, ny + 2), "dy": (nx + 2, ny + 2),
-                "zeta": (nx + 2, ny + 2), "h": (nx + 2, ny + 2), "zr": (nx + 4, ny + 4, nz),
+                "zeta": (nx + 2, ny + 2), "h": (nx + 2, ny + 2), "rmask": (nx + 2, ny + 2), "zr": (nx + 4, ny + 4, nz),
                 "zw": (nx + 4, ny + 4, nz + 1), "cw": (nx + 2, ny + 2, nz + 1)}[name]
 
     def get(self, name):

@@ -31,6 +31,20 @@ def rndtopo_geometry(nx, ny, npx=1, npy=1, rank=0, Lx=1e4, Ly=1e4, Htot=4e3, see
             np.zeros((nx + 2, ny + 2)), h)
 
 
+def island_mask(nx, ny, npx=1, npy=1, rank=0):
+    """rmask of one rank for bmask=.true. runs, (nx+2, ny+2) = Fortran (0:ny+1, 0:nx+1): a closed basin (0 in the
+    physical halo) with one round island, defined on GLOBAL indices so it does not depend on the decomposition."""
+    nxg, nyg = npx * nx, npy * ny
+    pj, pi = rank // npx, rank % npx
+    ig = np.arange(0, nxg + 2, dtype=np.float64)[:, None]
+    jg = np.arange(0, nyg + 2, dtype=np.float64)[None, :]
+    m = np.ones((nxg + 2, nyg + 2))
+    m[(ig - 0.3 * nxg) ** 2 + (jg - 0.6 * nyg) ** 2 <= (0.12 * min(nxg, nyg)) ** 2] = 0.0
+    m[0, :] = m[-1, :] = 0.0
+    m[:, 0] = m[:, -1] = 0.0
+    return m[pi * nx:pi * nx + nx + 2, pj * ny:pj * ny + ny + 2].copy()
+
+
 def resting_column_state(nx, ny, nz):
     """u = v = 0, w = -1 except 0 at the bottom (mg_testseamount.f90:119-123), in the model's (i,j,k) layout:
     numpy shapes (nz, ny+2, nx+1), (nz, ny+1, nx+2), (nz+1, ny+2, nx+2)."""

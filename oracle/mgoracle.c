@@ -22,8 +22,10 @@
  * netcdf-fortran, which the image lacks, and a hand-written `mpi` module), so
  * no oracle/_ref exists.
  *
- * Not restated (out of scope rows of SURVEY.md section 8): bmask=.true.
- * (row f3), aggressive coarsening (unimplemented in the reference itself,
+ * bmask=.true. (row f3) is restated too (masked coefficients, fill_halo_2D_bmask,
+ * fill_halo_4D, masked compute_rhs / correct_uvw) but the reference left no
+ * known answers for it: that branch is NOT pinned.
+ * Not restated (out of scope rows of SURVEY.md section 8): aggressive coarsening (unimplemented in the reference itself,
  * mg_intergrids.f90:243), nz==1 levels (dead, mg_grids.f90:485), netcdf output.
  */
 #include <math.h>
@@ -45,6 +47,7 @@ typedef struct {
   int cmatrix_real;    /* :20  1='real' 0='simple' */
   int relax_method;    /* :23  0=GS 1=RB 2=FC */
   int interp_linear;   /* :27  1='linear' 0='nearest' */
+  int bmask;           /* :35  boundary mask applied to the coefficients */
 } mgo_params;
 
 /* one grid level of one rank: mg_grids.f90:24-65 */
@@ -56,6 +59,7 @@ typedef struct {
   double *cA;                 /* (8,nz,0:ny+1,0:nx+1) */
   double *p, *b, *r;          /* (nz,0:ny+1,0:nx+1) */
   double *dx, *dy, *zeta, *h; /* (0:ny+1,0:nx+1) */
+  double *rmask;              /* (0:ny+1,0:nx+1): level 1 from the caller, coarser levels = 1 (mg_define_matrix.f90:78-79,157-161) */
   double *zr;                 /* (nz,-1:ny+2,-1:nx+2) */
   double *zw;                 /* (nz+1,-1:ny+2,-1:nx+2) */
   double *cw;                 /* (nz+1,0:ny+1,0:nx+1) */
@@ -241,7 +245,7 @@ static void halo_phase1(olev *L, double *a, const halo_desc *d) {
 }
 
 /* phase 2: receive = copy the neighbour's interior edge (its packed send buffer) */
-static void halo_phase2(oworld *W, int r, int l, field_fn f, const halo_desc *d) {
+static void halo_phase2x(oworld *W, int r, int l, field_fn f, const halo_desc *d, int mixed) {
   olev *L = &W->rk[r].lev[l];
   double *a = f(L);
   int nx = L->nx, ny = L->ny, nh = d->nh, nzz = d->nzz;
@@ -267,6 +271,7 @@ static void halo_phase2(oworld *W, int r, int l, field_fn f, const halo_desc *d)
       A(k, j, i) = B(k, j + sj, i + si);
   }
 #undef B
+  if (!mixed) return;
   /* phase 3: mixed corners copied from the already filled edge halo, mg_mpi_exchange.f90:720-743 */
   int S = L->neighb[0], E = L->neighb[1], N = L->neighb[2], Wn = L->neighb[3];
   int SW = L->neighb[4], SE = L->neighb[5], NE = L->neighb[6], NW = L->neighb[7];
@@ -289,6 +294,8 @@ static void halo_phase2(oworld *W, int r, int l, field_fn f, const halo_desc *d)
   }
 #undef A
 }
+static void halo_phase2(oworld *W, int r, int l, field_fn f, const halo_desc *d) { halo_phase2x(W, r, l, f, d, 1); }
+static void halo_phase2_exchange_only(oworld *W, int r, int l, field_fn f, const halo_desc *d) { halo_phase2x(W, r, l, f, d, 0); }
 
 static void fill_halo_all(oworld *W, int l, field_fn f, halo_desc d) {
   for (int r = 0; r < W->nranks; r++) halo_phase1(&W->rk[r].lev[l], f(&W->rk[r].lev[l]), &d);
@@ -304,6 +311,7 @@ static double *f_zeta(olev *L) { return L->zeta; }
 static double *f_h(olev *L) { return L->h; }
 static double *f_zr(olev *L) { return L->zr; }
 static double *f_zw(olev *L) { return L->zw; }
+static double *f_cA(olev *L) { return L->cA; }
 static double *f_dummy3(olev *L) { return L->dummy3; }
 
 static halo_desc HD(int nzz, int nh, char c) { halo_desc d; d.nzz = nzz; d.nh = nh; d.lbc = c; d.which = 0; return d; }
@@ -352,16 +360,31 @@ static void setup_zr_zw(oworld *W, olev *L) {
 
 /* ------------------------------------------------------------------ */
 /* mg_define_matrix.f90:211-680 define_matrix (bmask=.false.: umask=vmask=1) */
-static void define_matrix(olev *L, int lev) {
+static void define_matrix(olev *L, int lev, int bmask, int phase) {
   int nx = L->nx, ny = L->ny, nz = L->nz;
   const double one = 1.0, qrt = 0.25, hlf = 0.5;
   double *cA = L->cA, *cw = L->cw;
+  /* umask, vmask from rmask (:255-275) */
+  size_t n2m = (size_t)(ny + 2) * (nx + 2);
+  double *umask = (double *)malloc(n2m * sizeof(double)), *vmask = (double *)malloc(n2m * sizeof(double));
+  for (size_t q = 0; q < n2m; q++) { umask[q] = bmask ? 0.0 : 1.0; vmask[q] = bmask ? 0.0 : 1.0; }
+  if (bmask) {
+    for (int i = 1; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) umask[I2(L, j, i)] = L->rmask[I2(L, j, i - 1)] * L->rmask[I2(L, j, i)];
+    for (int i = 0; i <= nx + 1; i++) for (int j = 1; j <= ny + 1; j++) vmask[I2(L, j, i)] = L->rmask[I2(L, j - 1, i)] * L->rmask[I2(L, j, i)];
+  }
+#define UM(j, i) umask[I2(L, j, i)]
+#define VM(j, i) vmask[I2(L, j, i)]
+  int k = 1;
 #define ZR(k, j, i) L->zr[IZR(L, k, j, i)]
 #define ZW(k, j, i) L->zw[IZW(L, k, j, i)]
 #define DX(j, i) L->dx[I2(L, j, i)]
 #define DY(j, i) L->dy[I2(L, j, i)]
 #define CW(k, j, i) cw[I3P(L, k, j, i)]
 #define CA(s, k, j, i) cA[ICA(L, s, k, j, i)]
+  if (phase == 1) goto diagonal;
+  /* entries define_matrix never writes (parts of the halo) are undefined in the reference (allocate, mg_grids.f90:221);
+   * the restatement and the HIP path both define them as 0, on every call */
+  memset(cA, 0, (size_t)8 * nz * (ny + 2) * (nx + 2) * sizeof(double));
   if (lev == 1) { /* :283-306 */
     for (int i = 0; i <= nx + 1; i++)
       for (int j = 0; j <= ny + 1; j++) {
@@ -396,11 +419,11 @@ static void define_matrix(olev *L, int lev) {
       CW(k, j, i) = (Arz / (ZW(k, j, i) - ZR(k - 1, j, i))) * (one + sx * sx + sy * sy);
     }
   /* k = 1 :352-485 */
-  int k = 1;
+  k = 1;
   for (int i = 1; i <= nx; i++)
     for (int j = 1; j <= ny + 1; j++) {
       CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
-                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
       double t1 = ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
       double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i));
       CA(4, k, j, i) =
@@ -409,11 +432,19 @@ static void define_matrix(olev *L, int lev) {
           - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)))
           - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i) -
                    (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i));
+      if (bmask) /* :375-389 i,j cross terms at closed boundaries (the dy/dx pairing of the second term is the reference's) */
+        CA(4, k, j, i) = (CA(4, k, j, i)
+            - (hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
+                   ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
+                   (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * (UM(j - 1, i + 1) - UM(j - 1, i))
+               - hlf * ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DY(j, i)) * DX(j, i)) *
+                     ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) /
+                     (CW(k, j, i) + CW(k + 1, j, i)) * (UM(j, i + 1) - UM(j, i)))) * VM(j, i);
     }
   for (int i = 1; i <= nx + 1; i++)
     for (int j = 1; j <= ny; j++) {
       CA(6, k, j, i) = qrt * ((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i) +
-                              (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * one;
+                              (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) * UM(j, i);
       double t1 = ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
       double t2 = ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1));
       CA(7, k, j, i) =
@@ -422,50 +453,66 @@ static void define_matrix(olev *L, int lev) {
           - ((t1 * t1) / (CW(k, j, i) + CW(k + 1, j, i)) + (t2 * t2) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)))
           - qrt * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1) -
                    (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i));
+      if (bmask) /* :417-433 */
+        CA(7, k, j, i) = (CA(7, k, j, i)
+            - (hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
+                   ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
+                   (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * (VM(j + 1, i - 1) - VM(j, i - 1))
+               - hlf * ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DY(j, i)) * DX(j, i)) *
+                     ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) /
+                     (CW(k, j, i) + CW(k + 1, j, i)) * (VM(j + 1, i) - VM(j, i)))) * UM(j, i);
     }
   for (int i = 1; i <= nx + 1; i++)
     for (int j = 0; j <= ny; j++) {
       CA(5, k, j, i) =
           +hlf * ((hlf * (ZR(k, j + 1, i + 1) - ZR(k, j + 1, i - 1)) / DX(j + 1, i)) * DY(j + 1, i)) *
                   ((hlf * (ZR(k, j + 2, i) - ZR(k, j, i)) / DY(j + 1, i)) * DX(j + 1, i)) /
-                  (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * one * one
+                  (CW(k, j + 1, i) + CW(k + 1, j + 1, i)) * UM(j + 1, i) * VM(j + 1, i)
           + hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
                   ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
-                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * UM(j, i) * VM(j + 1, i - 1);
     }
   for (int i = 1; i <= nx + 1; i++)
     for (int j = 1; j <= ny + 1; j++) {
       CA(8, k, j, i) =
           -hlf * ((hlf * (ZR(k, j - 1, i + 1) - ZR(k, j - 1, i - 1)) / DX(j - 1, i)) * DY(j - 1, i)) *
                   ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) /
-                  (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * one * one
+                  (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * UM(j - 1, i) * VM(j, i)
           - hlf * ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)) *
                   ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
-                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * one * one;
+                  (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * UM(j, i) * VM(j, i - 1);
     }
   /* k = 2..nz-1 :492-559 */
   for (int i = 1; i <= nx; i++)
     for (int j = 1; j <= ny; j++)
-      for (k = 2; k <= nz - 1; k++) CA(2, k, j, i) = CW(k, j, i);
+      for (k = 2; k <= nz - 1; k++) {
+        CA(2, k, j, i) = CW(k, j, i);
+        if (bmask) /* :497-509 */
+          CA(2, k, j, i) = CA(2, k, j, i)
+              - qrt * ((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i) -
+                       (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)) * (UM(j, i + 1) - UM(j, i))
+              - qrt * ((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i) -
+                       (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) * (VM(j + 1, i) - VM(j, i));
+      }
   for (int i = 1; i <= nx; i++)
     for (int j = 1; j <= ny + 1; j++)
       for (k = 2; k <= nz - 1; k++) {
         CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
-                                (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * one;
+                                (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
         CA(4, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) *
-                          (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * one;
+                          (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * VM(j, i);
         CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
-                                 ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+                                 ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * VM(j, i);
       }
   for (int i = 1; i <= nx + 1; i++)
     for (int j = 1; j <= ny; j++)
       for (k = 2; k <= nz - 1; k++) {
         CA(6, k, j, i) = qrt * (((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                                ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                                ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
         CA(7, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) *
-                          (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * one;
+                          (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * UM(j, i);
         CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                                 ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                                 ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
       }
   /* k = nz :565-609 */
   k = nz;
@@ -477,9 +524,9 @@ static void define_matrix(olev *L, int lev) {
           (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) /
                (hlf * (DY(j, i) + DY(j - 1, i)))
            + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))
-                    + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * one;
+                    + ((hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)))) * VM(j, i);
       CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * one;
+                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * VM(j, i);
     }
   for (int i = 1; i <= nx + 1; i++)
     for (int j = 1; j <= ny; j++) {
@@ -487,10 +534,12 @@ static void define_matrix(olev *L, int lev) {
           (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) /
                (hlf * (DX(j, i) + DX(j, i - 1)))
            + qrt * (-((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))
-                    + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * one;
+                    + ((hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i)))) * UM(j, i);
       CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * one;
+                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
     }
+  if (phase == 0) { free(umask); free(vmask); return; }
+diagonal:
   /* diagonal :616-657 */
   for (int i = 1; i <= nx; i++)
     for (int j = 1; j <= ny; j++) {
@@ -512,6 +561,9 @@ static void define_matrix(olev *L, int lev) {
                        - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
                        - CA(6, k - 1, j, i + 1) - CA(8, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i);
     }
+  free(umask); free(vmask);
+#undef UM
+#undef VM
 #undef ZR
 #undef ZW
 #undef DX
@@ -575,8 +627,27 @@ static void define_matrices(oworld *W) {
     for (int r = 0; r < W->nranks; r++) setup_zr_zw(W, &W->rk[r].lev[l]); /* :174-178 */
     fill_halo_all(W, l, f_zr, HD(W->rk[0].lev[l].nz, 2, 0));              /* :184 */
     fill_halo_all(W, l, f_zw, HD(W->rk[0].lev[l].nz + 1, 2, 0));          /* :185 */
+    for (int r = 0; r < W->nranks; r++) { /* boundary mask of the level: :78-79 (level 1: the caller's), :157-161 */
+      olev *L = &W->rk[r].lev[l];
+      if (l > 0) {
+        size_t n2 = (size_t)(L->ny + 2) * (L->nx + 2);
+        for (size_t q = 0; q < n2; q++) L->rmask[q] = 1.0;
+        if (W->par.bmask) { /* fill_halo_2D_bmask, mg_mpi_exchange.f90:357-391 */
+          if (L->neighb[0] < 0) for (int i = 0; i <= L->nx + 1; i++) L->rmask[I2(L, 0, i)] = 0.0;
+          if (L->neighb[1] < 0) for (int j = 0; j <= L->ny + 1; j++) L->rmask[I2(L, j, L->nx + 1)] = 0.0;
+          if (L->neighb[2] < 0) for (int i = 0; i <= L->nx + 1; i++) L->rmask[I2(L, L->ny + 1, i)] = 0.0;
+          if (L->neighb[3] < 0) for (int j = 0; j <= L->ny + 1; j++) L->rmask[I2(L, j, 0)] = 0.0;
+        }
+      }
+    }
 #pragma omp parallel for schedule(static)
-    for (int r = 0; r < W->nranks; r++) define_matrix(&W->rk[r].lev[l], l + 1); /* :202 */
+    for (int r = 0; r < W->nranks; r++) define_matrix(&W->rk[r].lev[l], l + 1, W->par.bmask, 0); /* :202, up to :609 */
+    if (W->par.bmask) { /* fill_halo(lev,cA) :611-613 = fill_halo_4D: neighbour exchange only (physical sides untouched when bmask) */
+      halo_desc d = HD(8 * W->rk[0].lev[l].nz, 1, 0);
+      for (int r = 0; r < W->nranks; r++) halo_phase2_exchange_only(W, r, l, f_cA, &d);
+    }
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < W->nranks; r++) define_matrix(&W->rk[r].lev[l], l + 1, W->par.bmask, 1); /* diagonal :616-657 */
   }
 }
 
@@ -890,14 +961,19 @@ static int solve_p(oworld *W, double tol, int maxite, double *hist, double *bnor
 /* mg_compute_rhs.f90:14-379 compute_rhs (bmask=.false.)                */
 static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
   const double two = 2.0, hlf = 0.5, qrt = 0.25;
+  const int bmask = W->par.bmask;
+  (void)rmask_by_rank;
   int nzg = W->rk[0].lev[0].nz;
   for (int pass = 0; pass < 3; pass++) {
     for (int r = 0; r < W->nranks; r++) {
       orank *R = &W->rk[r];
       olev *L = &R->lev[0];
       int nx = L->nx, ny = L->ny, nz = L->nz;
-      const double *rm = rmask_by_rank ? rmask_by_rank[r] : NULL;
-#define RM(j, i) (rm ? rm[I2(L, j, i)] : 1.0)
+      const double *rm = L->rmask; /* the reference indexes the model's rmask as (j,i), mg_compute_rhs.f90:61,110 */
+#define RM(j, i) rm[I2(L, j, i)]
+      /* umask(j,i)=rmask(j,i-1)*rmask(j,i) for i>=1, vmask(j,i)=rmask(j-1,i)*rmask(j,i) for j>=1, else 0 (:56-72) */
+#define UMK(j, i) (bmask ? (((i) >= 1) ? RM(j, (i)-1) * RM(j, i) : 0.0) : 1.0)
+#define VMK(j, i) (bmask ? (((j) >= 1) ? RM((j)-1, i) * RM(j, i) : 0.0) : 1.0)
 #define U(i, j, k) R->u[(((size_t)((k)-1)) * (ny + 2) + (j)) * (nx + 1) + ((i)-1)]
 #define V(i, j, k) R->v[(((size_t)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
 #define Wv(i, j, k) R->w[(((size_t)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
@@ -924,10 +1000,10 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                     ZXDY(k, j, i - 1) * ZXDY(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1))) *
                        (hlf * (DX(j, i) + DX(j, i - 1))) * U(i, j, k)
                  - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-                        (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0) +
+                        (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i)) +
                     ZXDY(k, j, i - 1) * ZYDX(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * hlf *
-                        (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * 1.0 +
-                         hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * 1.0))) * 1.0;
+                        (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * VMK(j, i - 1) +
+                         hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * VMK(j + 1, i - 1)))) * UMK(j, i);
         for (int i = 1; i <= nx + 1; i++)
           for (int j = 1; j <= ny; j++)
             for (k = 2; k <= nz - 1; k++)
@@ -936,7 +1012,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                    - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                             ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                             ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                            ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+                            ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
         k = nz;
         for (int i = 1; i <= nx + 1; i++)
           for (int j = 1; j <= ny; j++)
@@ -945,7 +1021,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                  - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                           ZXDY(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                           ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                          ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * 1.0;
+                          ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
       } else if (pass == 1) {
         for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (int k = 1; k <= nz; k++)
           RHS(k, j, i) = UF(k, j, i + 1) - UF(k, j, i); /* :178-186 */
@@ -961,10 +1037,10 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                     ZYDX(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i))) *
                        hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k)
                  - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-                        (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0) +
+                        (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1)) +
                     ZXDY(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * hlf *
-                        (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * 1.0 +
-                         hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * 1.0))) * 1.0;
+                        (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * UMK(j - 1, i) +
+                         hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * UMK(j - 1, i + 1)))) * VMK(j, i);
         for (int i = 1; i <= nx; i++)
           for (int j = 1; j <= ny + 1; j++)
             for (k = 2; k <= nz - 1; k++)
@@ -973,7 +1049,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                    - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                             ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                             ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                            ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+                            ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
         k = nz;
         for (int i = 1; i <= nx; i++)
           for (int j = 1; j <= ny + 1; j++)
@@ -982,7 +1058,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
                  - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
                           ZYDX(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
                           ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                          ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * 1.0;
+                          ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
       } else {
         for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (int k = 1; k <= nz; k++)
           RHS(k, j, i) = RHS(k, j, i) + UF(k, j + 1, i) - UF(k, j, i); /* :279-287 */
@@ -992,32 +1068,32 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
           for (int j = 1; j <= ny; j++)
             for (int k = 2; k <= nz; k++)
               WF(k, j, i) = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-                            qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * 1.0 +
-                                         ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * 1.0 +
-                                         ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
-                                         ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0);
+                            qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) +
+                                         ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1) +
+                                         ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
+                                         ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1));
         for (int i = 1; i <= nx; i++)
           for (int j = 1; j <= ny; j++)
             for (int k = 2; k <= nz; k++)
               WF(k, j, i) = WF(k, j, i) -
-                            qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * 1.0 +
-                                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * 1.0 +
-                                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
-                                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+                            qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) +
+                                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i) +
+                                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
+                                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
         int k = nz + 1;
         for (int i = 1; i <= nx; i++)
           for (int j = 1; j <= ny; j++)
             WF(k, j, i) = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-                          hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * 1.0 +
-                                       ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * 1.0) -
-                          hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * 1.0 +
-                                       ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * 1.0);
+                          hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
+                                       ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1)) -
+                          hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
+                                       ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
         for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (k = 1; k <= nz; k++)
           RHS(k, j, i) = RHS(k, j, i) + WF(k + 1, j, i) - WF(k, j, i); /* :362-370 */
       }
     }
     /* fill_halo(1,uf,lbc_null='u') :171 / fill_halo(1,vf,lbc_null='v') :272 */
-    if (pass < 2) {
+    if (pass < 2 && !bmask) { /* :170, :271 */
       halo_desc d = HD(nzg, 1, pass == 0 ? 'u' : 'v');
       for (int r = 0; r < W->nranks; r++) halo_phase1(&W->rk[r].lev[0], W->rk[r].dum_nz, &d);
       /* phase 2 needs a field accessor: park the per-rank pointers in dummy3 of level 1 */
@@ -1027,6 +1103,8 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
     }
   }
 #undef RM
+#undef UMK
+#undef VMK
 #undef V
 #undef Wv
 #undef ZW
@@ -1044,6 +1122,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
 /* mg_correct_uvw.f90:15-115 correct_uvw (bmask=.false.) */
 static void correct_uvw(oworld *W) {
   const double one = 1.0, hlf = 0.5;
+  const int bmask = W->par.bmask;
   for (int r = 0; r < W->nranks; r++) {
     orank *R = &W->rk[r];
     olev *L = &R->lev[0];
@@ -1053,11 +1132,11 @@ static void correct_uvw(oworld *W) {
 #define P(k, j, i) L->p[I3(L, k, j, i)]
     for (int i = 1; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
       double dxu = hlf * (L->dx[I2(L, j, i)] + L->dx[I2(L, j, i - 1)]);
-      U(i, j, k) = U(i, j, k) - one / dxu * (P(k, j, i) - P(k, j, i - 1)) * 1.0;
+      U(i, j, k) = U(i, j, k) - one / dxu * (P(k, j, i) - P(k, j, i - 1)) * (bmask ? L->rmask[I2(L, j, i - 1)] * L->rmask[I2(L, j, i)] : 1.0);
     }
     for (int i = 0; i <= nx + 1; i++) for (int j = 1; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
       double dyv = hlf * (L->dy[I2(L, j, i)] + L->dy[I2(L, j - 1, i)]);
-      V(i, j, k) = V(i, j, k) - one / dyv * (P(k, j, i) - P(k, j - 1, i)) * 1.0;
+      V(i, j, k) = V(i, j, k) - one / dyv * (P(k, j, i) - P(k, j - 1, i)) * (bmask ? L->rmask[I2(L, j - 1, i)] * L->rmask[I2(L, j, i)] : 1.0);
     }
     for (int i = 0; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) {
       for (int k = 2; k <= nz; k++) {
@@ -1094,6 +1173,7 @@ void *mgo_create(int nxl, int nyl, int nzl, int npx, int npy, const mgo_params *
       size_t n2 = (size_t)(L->ny + 2) * (L->nx + 2), n3 = n2 * L->nz;
       L->cA = dalloc(n3 * 8); L->p = dalloc(n3); L->b = dalloc(n3); L->r = dalloc(n3);
       L->dx = dalloc(n2); L->dy = dalloc(n2); L->zeta = dalloc(n2); L->h = dalloc(n2);
+      L->rmask = dalloc(n2); for (size_t q = 0; q < n2; q++) L->rmask[q] = 1.0;
       L->zr = dalloc((size_t)(L->ny + 4) * (L->nx + 4) * L->nz);
       L->zw = dalloc((size_t)(L->ny + 4) * (L->nx + 4) * (L->nz + 1));
       L->cw = dalloc(n2 * (L->nz + 1));
@@ -1116,7 +1196,7 @@ void mgo_destroy(void *h) {
     orank *R = &W->rk[r];
     for (int l = 0; l < W->nlevs; l++) {
       olev *L = &R->lev[l];
-      free(L->cA); free(L->p); free(L->b); free(L->r); free(L->dx); free(L->dy); free(L->zeta); free(L->h);
+      free(L->cA); free(L->p); free(L->b); free(L->r); free(L->dx); free(L->dy); free(L->zeta); free(L->h); free(L->rmask);
       free(L->zr); free(L->zw); free(L->cw); free(L->dzw); free(L->zxdy); free(L->zydx);
       if (l > 0) { free(L->dummy3); for (int q = 0; q < 4; q++) free(L->tmp2[q]); }
     }
@@ -1135,7 +1215,7 @@ void mgo_level_info(void *h, int rank, int lev, int *out) {
   memcpy(out + 12, L->neighb, sizeof(int) * 8);
 }
 
-/* field ids: 0 p,1 b,2 r,3 cA,4 dx,5 dy,6 zeta,7 h,8 zr,9 zw,10 cw,11 u,12 v,13 w */
+/* field ids: 0 p,1 b,2 r,3 cA,4 dx,5 dy,6 zeta,7 h,8 zr,9 zw,10 cw,11 u,12 v,13 w,14 rmask */
 double *mgo_field(void *h, int rank, int lev, int id) {
   orank *R = &((oworld *)h)->rk[rank];
   olev *L = &R->lev[lev - 1];
@@ -1143,7 +1223,7 @@ double *mgo_field(void *h, int rank, int lev, int id) {
     case 0: return L->p; case 1: return L->b; case 2: return L->r; case 3: return L->cA;
     case 4: return L->dx; case 5: return L->dy; case 6: return L->zeta; case 7: return L->h;
     case 8: return L->zr; case 9: return L->zw; case 10: return L->cw;
-    case 11: return R->u; case 12: return R->v; case 13: return R->w;
+    case 11: return R->u; case 12: return R->v; case 13: return R->w; case 14: return L->rmask;
   }
   return NULL;
 }

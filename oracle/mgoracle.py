@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmgoracle.so")
 
 FIELD = {"p": 0, "b": 1, "r": 2, "cA": 3, "dx": 4, "dy": 5, "zeta": 6, "h": 7,
-         "zr": 8, "zw": 9, "cw": 10, "u": 11, "v": 12, "w": 13}
+         "zr": 8, "zw": 9, "cw": 10, "u": 11, "v": 12, "w": 13, "rmask": 14}
 METHOD = {"GS": 0, "Gauss-Seidel": 0, "RB": 1, "Red-Black": 1, "FC": 2, "Four-Color": 2}
 
 
@@ -21,7 +21,7 @@ class Params(C.Structure):
     """The &nhparam members the path reads (mg_namelist.f90:11-35)."""
     _fields_ = [("solver_prec", C.c_double), ("solver_maxiter", C.c_int), ("nsmall", C.c_int),
                 ("ns_coarsest", C.c_int), ("ns_pre", C.c_int), ("ns_post", C.c_int),
-                ("cmatrix_real", C.c_int), ("relax_method", C.c_int), ("interp_linear", C.c_int)]
+                ("cmatrix_real", C.c_int), ("relax_method", C.c_int), ("interp_linear", C.c_int), ("bmask", C.c_int)]
 
 
 def build(force=False):
@@ -68,9 +68,10 @@ class Oracle:
     """One emulated MPI world of npx*npy ranks, local block nx x ny x nz each."""
 
     def __init__(self, nx, ny, nz, npx=1, npy=1, relax_method="RB", solver_prec=1e-6, solver_maxiter=50,
-                 nsmall=8, ns_coarsest=40, ns_pre=3, ns_post=2, cmatrix="real", interp_type="linear"):
+                 nsmall=8, ns_coarsest=40, ns_pre=3, ns_post=2, cmatrix="real", interp_type="linear", bmask=False):
         self.par = Params(solver_prec, solver_maxiter, nsmall, ns_coarsest, ns_pre, ns_post,
-                          1 if cmatrix == "real" else 0, METHOD[relax_method], 1 if interp_type == "linear" else 0)
+                          1 if cmatrix == "real" else 0, METHOD[relax_method], 1 if interp_type == "linear" else 0,
+                          1 if bmask else 0)
         self.nx, self.ny, self.nz, self.npx, self.npy = nx, ny, nz, npx, npy
         self.nranks = npx * npy
         self.h = lib().mgo_create(nx, ny, nz, npx, npy, C.byref(self.par))
@@ -102,7 +103,7 @@ class Oracle:
         l1 = self.level_info(1, rank)
         shape = {"p": (nx + 2, ny + 2, nz), "b": (nx + 2, ny + 2, nz), "r": (nx + 2, ny + 2, nz),
                  "cA": (nx + 2, ny + 2, nz, 8), "dx": (nx + 2, ny + 2), "dy": (nx + 2, ny + 2),
-                 "zeta": (nx + 2, ny + 2), "h": (nx + 2, ny + 2), "zr": (nx + 4, ny + 4, nz),
+                 "zeta": (nx + 2, ny + 2), "h": (nx + 2, ny + 2), "rmask": (nx + 2, ny + 2), "zr": (nx + 4, ny + 4, nz),
                  "zw": (nx + 4, ny + 4, nz + 1), "cw": (nx + 2, ny + 2, nz + 1),
                  "u": (l1["nz"], l1["ny"] + 2, l1["nx"] + 1), "v": (l1["nz"], l1["ny"] + 1, l1["nx"] + 2),
                  "w": (l1["nz"] + 1, l1["ny"] + 2, l1["nx"] + 2)}[name]

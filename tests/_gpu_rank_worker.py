@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, npx, npy, port, nx, ny, nz, nsmall = (int(a) for a in sys.argv[1:10])
     method = sys.argv[10]
+    bmask = len(sys.argv) > 11 and sys.argv[11] == "bmask"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -25,10 +26,12 @@ def main():
 
     nhydro.set_verbose(0)
     comm = Comm(device="cuda")
-    par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6)
+    par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6, bmask=1 if bmask else 0)
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
-    mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+    from mgroms_amd.testcases import island_mask
+    rmask = island_mask(nx, ny, npx, npy, rank) if bmask else None
+    mg.nhydro_matrices(dx, dy, zeta, h, rmask, 4e3, 0.0, 0.0)
     u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
     nhydro.compute_rhs(u, v, w)
     import time
@@ -36,7 +39,11 @@ def main():
     n, hist = mg.solve_p(1e-9, 3)
     t_solve = time.time() - t0
 
-    o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6)
+    o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6, bmask=bmask)
+    if bmask:  # masked coefficients: rebuild the oracle's matrices with every rank's mask in place
+        for r in range(o.nranks):
+            o.field("rmask", 1, r)[...] = island_mask(nx, ny, npx, npy, r)
+        o.matrices(4e3, 0.0, 0.0)
     o.compute_rhs()
     no, ho, _ = o.solve_p(1e-9, 3)
     assert mg.nlevs() == o.nlevs

@@ -27,10 +27,12 @@ def _free_port():
     (2, 2, 32, 32, 16, 32, "FC"),   # nsmall=32: gathered from level 2 on (every coarse level runs redundantly)
     (4, 1, 16, 32, 8, 16, "FC"),    # 4x1 with nsmall=16: two consecutive gathers (4 -> 2 -> 1 ranks), as bench.py uses for N>1
     (2, 1, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
+    (2, 2, 16, 16, 8, 8, "FC+bmask"),  # bmask=.true.: masked coefficients + the 4-D cA halo exchange of define_matrix
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     world, port = npx * npy, _free_port()
-    args = [str(a) for a in (world, npx, npy, port, nx, ny, nz, nsmall)] + [method]
+    method, _, opt = method.partition("+")
+    args = [str(a) for a in (world, npx, npy, port, nx, ny, nz, nsmall)] + [method] + ([opt] if opt else [])
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r)] + args,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []

@@ -162,6 +162,44 @@ def test_compute_rhs_and_correct_uvw(mg):
     assert np.array_equal(u, o.field("u")) and np.array_equal(v, o.field("v")) and np.array_equal(w, o.field("w"))
 
 
+@pytest.mark.parametrize("dims,geom", [((32, 32, 8), "seamount"), ((64, 32, 16), "rndtopo")])
+def test_bmask_bitwise(mg, dims, geom):
+    """bmask=.true.: masked coefficients on every level, masked compute_rhs / correct_uvw and the
+    whole solve, bit for bit against the oracle.  The reference holds no known answers for this branch, so the
+    oracle's bmask branch is itself unpinned: this test proves GPU == restatement, no more."""
+    from oracle.mgoracle import Oracle, seamount_geometry, rndtopo_geometry
+    from mgroms_amd.testcases import island_mask
+    nx, ny, nz = dims
+    kw = dict(relax_method="FC", solver_prec=1e-9, solver_maxiter=6)
+    mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(bmask=1, **kw))
+    dx, dy, zeta, h = (seamount_geometry if geom == "seamount" else rndtopo_geometry)(nx, ny, 1, 1, 0)
+    rmask = island_mask(nx, ny)
+    mg.nhydro_matrices(dx, dy, zeta, h, rmask, 4e3, 0.0, 0.0)
+    o = Oracle(nx, ny, nz, 1, 1, bmask=True, **kw)
+    for name, a in (("dx", dx), ("dy", dy), ("zeta", zeta), ("h", h), ("rmask", rmask)):
+        o.field(name)[...] = a
+    o.matrices(4e3, 0.0, 0.0)
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        for name in ("rmask", "cw", "cA"):
+            a, b = g.get(name), o.field(name, lev)
+            assert np.array_equal(a, b), (lev, name, np.abs(a - b).max())
+    u, v, w = _uvw(nx, ny, nz, seed=9)
+    o.field("u")[...] = u; o.field("v")[...] = v; o.field("w")[...] = w
+    mg.nhydro.compute_rhs(u, v, w, rmask)
+    o.compute_rhs()
+    assert np.array_equal(mg.grid(1).b, o.field("b"))
+    mg.nhydro_solve(u, v, w, rmask)
+    n, hist, _ = o.nhydro_solve()
+    assert hist[-1] < 0.1 * hist[0]  # the masked system is solvable and the cycle converges on it
+    assert np.array_equal(mg.grid(1).p, o.field("p"))
+    assert np.array_equal(u, o.field("u")) and np.array_equal(v, o.field("v")) and np.array_equal(w, o.field("w"))
+    # without rmask the masked set-up must refuse, not guess
+    from mgroms_amd._lib import MgxError
+    with pytest.raises(MgxError):
+        mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+
+
 def test_solve_fc_matches_oracle_and_golden(mg, golden):
     g = golden["seamount_64x64x16_FC_1rank"]
     o = _setup(mg, 64, 64, 16)
