@@ -71,8 +71,14 @@ contains
     real(kind=rp), dimension(:,:), pointer, intent(in) :: rmask
     real(kind=rp)                         , intent(in) :: hc, theta_b, theta_s
     real(kind=rp), dimension(:,:), allocatable :: a, b, c, d   ! contiguous copies of the assumed-shape arguments
+    real(kind=rp), dimension(:,:), allocatable, target :: m
     allocate(a, source=dx); allocate(b, source=dy); allocate(c, source=zeta); allocate(d, source=h)
-    call mgx_check(mgx_matrices(a, b, c, d, c_null_ptr, hc, theta_b, theta_s), 'nhydro_matrices')
+    if (associated(rmask)) then   ! only read by the library when bmask=.true.
+       allocate(m, source=rmask)
+       call mgx_check(mgx_matrices(a, b, c, d, c_loc(m), hc, theta_b, theta_s), 'nhydro_matrices')
+    else
+       call mgx_check(mgx_matrices(a, b, c, d, c_null_ptr, hc, theta_b, theta_s), 'nhydro_matrices')
+    endif
   end subroutine nhydro_matrices
 
   !--------------------------------------------------------------  (nhydro.f90:53-102)

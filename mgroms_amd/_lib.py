@@ -58,6 +58,10 @@ _SIGS = {
     "mgx_time_relax": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_time_residual": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_counters": (C.c_int, [C.POINTER(C.c_longlong)]),
+    "mgx_p2p_handle_bytes": (C.c_int, []),
+    "mgx_p2p_prepare": (C.c_int, [C.c_void_p]),
+    "mgx_p2p_connect": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgx_p2p_exchanges": (C.c_longlong, []),
     "mgx_last_error": (C.c_char_p, []),
     "mgx_version": (C.c_char_p, []),
 }

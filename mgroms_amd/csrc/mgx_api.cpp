@@ -36,7 +36,8 @@ void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, S
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
-void mgxk_halo_pack(hipStream_t, const LevView *, double *, double *, int, int);
+void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, unsigned long long *const *, const int *, unsigned long long,
+                   unsigned int *, int *, int);
 void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
 void mgxk_gather_place(hipStream_t, const LevView *, double *, const double *, int, int, int, int);
@@ -70,6 +71,8 @@ struct Level {
   int group[4], ngroup;
   size_t n3js;  // doubles in one JS array
   bool r_halo_stale = false, b_halo_stale = false;  // deferred neighbour exchanges (multi-rank)
+  size_t p2p_off[8][2];         // doubles into the receive slab: direction x parity
+  unsigned long long p2p_seq = 0;  // exchanges done on this level through the peer-to-peer transport
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
 };
 
@@ -86,6 +89,15 @@ struct State {
   double *d_scalar = nullptr; double *h_scalar = nullptr;
   double *ref_scratch = nullptr; size_t ref_scratch_n = 0;  // reference-layout staging (8 x level-1 field)
   double *xbuf[16]; size_t xbuf_n = 0;                       // 8 send + 8 receive halo buffers
+  // peer-to-peer halo transport (mgx_p2p_prepare / mgx_p2p_connect): receive slab + flags in fine-grained device memory,
+  // the same slab and flags of every other rank opened through hipIpc
+  bool p2p_ready = false, p2p_on = false;
+  double *p2p_slab = nullptr; size_t p2p_slab_n = 0;
+  unsigned long long *p2p_flags = nullptr;
+  std::vector<double *> peer_slab; std::vector<unsigned long long *> peer_flags;
+  unsigned int *p2p_counter = nullptr;
+  int *p2p_err = nullptr;   // host-mapped
+  long long n_p2p = 0;
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
   std::vector<void *> allocs;
   int verbose = 1;
@@ -99,6 +111,8 @@ struct State {
 };
 
 State S;
+int sync_stream();
+void p2p_release();
 
 int fail(const char *fmt, ...) {
   char buf[512];
@@ -202,10 +216,29 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
     const int c = L.nz * ((d == 0 || d == 2) ? L.nx : ((d == 1 || d == 3) ? L.ny : 1));
     peer[n] = nb[d]; cnt[n] = c; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d]; n++;
   }
-  if (n) {
+  if (n && S.p2p_on) {  // push into the neighbours' receive buffers over xGMI, then wait on the local flags: no host step
+    static const int opp[8] = {2, 3, 0, 1, 6, 7, 4, 5};
+    const unsigned long long seq = ++L.p2p_seq;
+    const int par = (int)(seq & 1), li = (int)(&L - &S.lev[0]);
+    double *rbuf[8], *lbuf[8];
+    unsigned long long *rflag[8], *lflag[8];
+    for (int d = 0; d < 8; d++) {
+      rbuf[d] = lbuf[d] = nullptr; rflag[d] = lflag[d] = nullptr;
+      if (nb[d] < 0) continue;
+      rbuf[d] = S.peer_slab[nb[d]] + L.p2p_off[opp[d]][par];
+      rflag[d] = S.peer_flags[nb[d]] + (li * 8 + opp[d]) * 2 + par;
+      lbuf[d] = S.p2p_slab + L.p2p_off[d][par];
+      lflag[d] = S.p2p_flags + (li * 8 + d) * 2 + par;
+    }
+    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, rflag, present, seq, S.p2p_counter, S.p2p_err, 0);
+    mgxk_halo_p2p(S.stream, &L.v, a, lbuf, lflag, present, seq, S.p2p_counter, S.p2p_err, 1);
+    S.n_launch += 2; S.n_p2p++;
+  } else if (n) {
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf, present, 0); S.n_launch++;       // all edges + corners, one launch
     CHK(exchange(n, peer, sb, rb, cnt));
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf + 8, present, 1); S.n_launch++;
+  }
+  if (n) {
     int m[4];
     const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
     bool any = false;
@@ -296,7 +329,7 @@ int global_sum(const Level &L, double *out) {
     if (S.ar(S.ctx, S.d_scalar, 1)) return fail("allreduce callback failed");
   }
   HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, sizeof(double), hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   *out = S.h_scalar[0] * (L.npx * L.npy) / (S.lev[0].npx * S.lev[0].npy);
   return 0;
 }
@@ -565,7 +598,7 @@ int define_matrices() {
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
     if (S.no_mf || S.par.bmask) L.v.zy = L.v.zx = nullptr;  // masked coefficients are not rebuilt from the slopes
   }
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   S.have_matrix = true;
   return 0;
 }
@@ -600,6 +633,29 @@ int upload_uvw(const double *u, const double *v, const double *w) {
 }
 
 bool streq(const char *a, const char *b) { return strcmp(a, b) == 0; }
+
+// ---- peer-to-peer halo transport: set-up / tear-down ---------------------------------------------------------
+void p2p_release() {
+  for (int r = 0; r < (int)S.peer_slab.size(); r++) {
+    if (r == S.rank) continue;
+    if (S.peer_slab[r]) (void)hipIpcCloseMemHandle(S.peer_slab[r]);
+    if (S.peer_flags[r]) (void)hipIpcCloseMemHandle(S.peer_flags[r]);
+  }
+  S.peer_slab.clear(); S.peer_flags.clear();
+  if (S.p2p_slab) (void)hipFree(S.p2p_slab);
+  if (S.p2p_flags) (void)hipFree(S.p2p_flags);
+  if (S.p2p_counter) (void)hipFree(S.p2p_counter);
+  if (S.p2p_err) (void)hipHostFree(S.p2p_err);
+  S.p2p_slab = nullptr; S.p2p_flags = nullptr; S.p2p_counter = nullptr; S.p2p_err = nullptr;
+  S.p2p_ready = S.p2p_on = false;
+}
+
+// stream synchronise + the peer-to-peer error word (a neighbour that never raised its flag)
+int sync_stream() {
+  HIPCHK(hipStreamSynchronize(S.stream));
+  if (S.p2p_err && *S.p2p_err) { *S.p2p_err = 0; return fail("peer-to-peer halo exchange timed out waiting for a neighbour"); }
+  return 0;
+}
 
 int apply_params(const mgx_params &p) {
   if (streq(p.relax_method, "GS") || streq(p.relax_method, "Gauss-Seidel")) S.method = M_GS;
@@ -683,6 +739,7 @@ int mgx_read_namelist(const char *path, mgx_params *p) {
 
 void mgx_clean(void) {
   if (S.stream || S.inited) hipStreamSynchronize(S.stream);
+  p2p_release();
   for (void *q : S.allocs) hipFree(q);
   if (S.h_scalar) hipHostFree(S.h_scalar);
   tt_collect();
@@ -780,7 +837,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_w, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
   CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
@@ -823,7 +880,7 @@ int mgx_compute_rhs(const double *u, const double *v, const double *w, const dou
   if (!S.have_matrix) return fail("mgx_matrices must be called before compute_rhs");
   CHK(upload_uvw(u, v, w));
   CHK(compute_rhs_dev());
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   return 0;
 }
 
@@ -842,7 +899,7 @@ int mgx_solve(double *u, double *v, double *w, const double *rmask) {
   HIPCHK(hipMemcpyAsync(u, S.d_u, nu * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   HIPCHK(hipMemcpyAsync(v, S.d_v, nv * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   HIPCHK(hipMemcpyAsync(w, S.d_w, nw * sizeof(double), hipMemcpyDeviceToHost, S.stream));
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   return 0;
 }
 
@@ -876,20 +933,20 @@ int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist) {
   if (!S.have_matrix) return fail("no matrix: call mgx_matrices (or mgx_set_field(lev, MGX_CA, ...)) first");
   return solve_p(tol, maxite, nite, res, hist);
 }
-int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
-int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
-int mgx_vcycle2(int lev1, int lev2) { NEED_LEV(lev1); NEED_LEV(lev2); if (lev2 < lev1) return fail("Vcycle2: lev2 < lev1"); CHK(vcycle2(lev1, lev2)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
-int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); CHK(sync_stream()); return 0; }
+int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); CHK(sync_stream()); return 0; }
+int mgx_vcycle2(int lev1, int lev2) { NEED_LEV(lev1); NEED_LEV(lev2); if (lev2 < lev1) return fail("Vcycle2: lev2 < lev1"); CHK(vcycle2(lev1, lev2)); CHK(sync_stream()); return 0; }
+int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); CHK(sync_stream()); return 0; }
 int mgx_residual(int lev, double *res) { NEED_LEV(lev); double r; CHK(residual(lev, &r)); if (res) *res = r; return 0; }
-int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
-int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); HIPCHK(hipStreamSynchronize(S.stream)); return 0; }
+int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); CHK(sync_stream()); return 0; }
+int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); CHK(sync_stream()); return 0; }
 int mgx_fill_halo(int lev, int field) {
   NEED_LEV(lev);
   Level &L = S.lev[lev - 1];
   double *a = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : (field == MGX_R ? L.v.r : nullptr));
   if (!a) return fail("fill_halo: field %d is not one of p,b,r", field);
   CHK(fill_halo_js(L, a));
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   return 0;
 }
 
@@ -913,6 +970,10 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "tictoc")) S.tictoc = value;
   else if (streq(name, "exact_halos")) S.exact_halos = value;
   else if (streq(name, "verbose")) S.verbose = value;
+  else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
+    if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
+    S.p2p_on = value != 0;
+  }
   else return fail("unknown option '%s'", name);
   return 0;
 }
@@ -980,7 +1041,7 @@ int mgx_get_field(int lev, int field, double *host) {
   } else if (!field_ptr(L, field, &a, &n)) {
     HIPCHK(hipMemcpyAsync(host, a, n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   } else return fail("get_field: unknown field id %d", field);
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   return 0;
 }
 
@@ -1002,7 +1063,7 @@ int mgx_set_field(int lev, int field, const double *host) {
   } else if (!field_ptr(L, field, &a, &n)) {
     HIPCHK(hipMemcpyAsync(a, host, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
   } else return fail("set_field: unknown field id %d", field);
-  HIPCHK(hipStreamSynchronize(S.stream));
+  CHK(sync_stream());
   return 0;
 }
 
@@ -1023,5 +1084,57 @@ static int time_op(int lev, int reps, float *ms, int which) {
 int mgx_time_relax(int lev, int reps, float *ms) { return time_op(lev, reps, ms, 0); }
 int mgx_time_residual(int lev, int reps, float *ms) { return time_op(lev, reps, ms, 1); }
 int mgx_counters(long long *out) { out[0] = S.n_launch; out[1] = S.n_halo; out[2] = S.n_exch; out[3] = S.n_allred; return 0; }
+long long mgx_p2p_exchanges(void) { return S.n_p2p; }
+
+int mgx_p2p_prepare(void *handles_out) {
+  NEED_INIT();
+  if (S.p2p_slab) return fail("mgx_p2p_prepare called twice");
+  size_t off = 0;
+  for (auto &L : S.lev)
+    for (int d = 0; d < 8; d++) {
+      const size_t c = (size_t)L.nz * ((d == 0 || d == 2) ? L.nx : ((d == 1 || d == 3) ? L.ny : 1));
+      for (int par = 0; par < 2; par++) { L.p2p_off[d][par] = off; off += (c + 31) / 32 * 32; }
+      L.p2p_seq = 0;
+    }
+  S.p2p_slab_n = off;
+  HIPCHK(hipExtMallocWithFlags((void **)&S.p2p_slab, off * sizeof(double), hipDeviceMallocFinegrained));
+  HIPCHK(hipExtMallocWithFlags((void **)&S.p2p_flags, 4096 * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+  HIPCHK(hipMalloc((void **)&S.p2p_counter, 64));
+  HIPCHK(hipHostMalloc((void **)&S.p2p_err, 64, hipHostMallocMapped));
+  *S.p2p_err = 0;
+  HIPCHK(hipMemset(S.p2p_slab, 0, off * sizeof(double)));
+  HIPCHK(hipMemset(S.p2p_flags, 0, 4096 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(S.p2p_counter, 0, 64));
+  HIPCHK(hipDeviceSynchronize());
+  hipIpcMemHandle_t h[2];
+  HIPCHK(hipIpcGetMemHandle(&h[0], S.p2p_slab));
+  HIPCHK(hipIpcGetMemHandle(&h[1], S.p2p_flags));
+  memcpy(handles_out, h, sizeof h);
+  return 0;
+}
+
+int mgx_p2p_handle_bytes(void) { return (int)(2 * sizeof(hipIpcMemHandle_t)); }
+
+int mgx_p2p_connect(const void *all_handles, int nranks) {
+  NEED_INIT();
+  if (!S.p2p_slab) return fail("mgx_p2p_connect: call mgx_p2p_prepare first");
+  if (nranks != S.nranks) return fail("mgx_p2p_connect: %d handle sets for %d ranks", nranks, S.nranks);
+  if ((int)S.lev.size() * 16 > 4096) return fail("mgx_p2p_connect: too many levels");
+  S.peer_slab.assign(nranks, nullptr); S.peer_flags.assign(nranks, nullptr);
+  S.peer_slab[S.rank] = S.p2p_slab; S.peer_flags[S.rank] = S.p2p_flags;
+  std::vector<char> need(nranks, 0);  // only the ranks that are a neighbour on some level are opened
+  for (auto &L : S.lev) for (int d = 0; d < 8; d++) if (L.neighb[d] >= 0) need[L.neighb[d]] = 1;
+  const hipIpcMemHandle_t *h = (const hipIpcMemHandle_t *)all_handles;
+  for (int r = 0; r < nranks; r++) {
+    if (r == S.rank || !need[r]) continue;
+    void *p = nullptr, *f = nullptr;
+    if (hipIpcOpenMemHandle(&p, h[2 * r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return fail("hipIpcOpenMemHandle(slab of rank %d) failed", r); }
+    S.peer_slab[r] = (double *)p;
+    if (hipIpcOpenMemHandle(&f, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return fail("hipIpcOpenMemHandle(flags of rank %d) failed", r); }
+    S.peer_flags[r] = (unsigned long long *)f;
+  }
+  S.p2p_ready = true; S.p2p_on = true;
+  return 0;
+}
 
 }  // extern "C"

@@ -776,9 +776,11 @@ __global__ void k_halo_mixed_corners(LevView L, double *__restrict__ a, int mSW,
 
 // pack / unpack of the 8 exchange buffers (edges nz*nx, nz*ny; corners nz).  dir: 0 S,1 E,2 N,3 W,4 SW,5 SE,6 NE,7 NW.
 // pack reads the interior edge that the neighbour in direction `dir` needs; unpack writes my halo on side `dir`.
-__global__ void k_halo_pack(LevView L, double *__restrict__ a, double *__restrict__ buf, int dir, int unpack) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+// all present directions in one launch: blockIdx.z = direction (absent ones return), buffers passed by value.
+// Buffer element (q,k) of an edge sits at k*n + q (q = position along the edge, lane-contiguous), so the writes of a
+// push into a neighbour GPU's memory leave each wave as whole 512-byte runs.
+struct HaloBufs { double *b[8]; int present[8]; };
+__device__ __forceinline__ bool halo_elem(const LevView &L, int dir, int q, int k, int unpack, long long &e, long long &t) {
   const int nx = L.nx, ny = L.ny;
   int i, j, n;
   switch (dir) {
@@ -791,36 +793,69 @@ __global__ void k_halo_pack(LevView L, double *__restrict__ a, double *__restric
     case 6: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? ny + 1 : ny; break;
     default: n = 1; i = unpack ? 0 : 1; j = unpack ? ny + 1 : ny; break;
   }
-  if (q >= n) return;
-  const long long e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
-  const long long t = (long long)q * L.nz + k;
-  if (unpack) a[e] = buf[t]; else buf[t] = a[e];
+  if (q >= n) return false;
+  e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
+  t = (long long)k * n + q;
+  return true;
 }
-
-// all present directions in one launch: blockIdx.z = direction (absent ones return), buffers passed by value
-struct HaloBufs { double *b[8]; int present[8]; };
 __global__ void k_halo_pack_all(LevView L, double *__restrict__ a, HaloBufs hb, int unpack) {
   const int dir = blockIdx.z;
   if (!hb.present[dir]) return;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const int nx = L.nx, ny = L.ny;
-  int i, j, n;
-  switch (dir) {
-    case 0: n = nx; i = q + 1; j = unpack ? 0 : 1; break;
-    case 1: n = ny; j = q + 1; i = unpack ? nx + 1 : nx; break;
-    case 2: n = nx; i = q + 1; j = unpack ? ny + 1 : ny; break;
-    case 3: n = ny; j = q + 1; i = unpack ? 0 : 1; break;
-    case 4: n = 1; i = unpack ? 0 : 1; j = unpack ? 0 : 1; break;
-    case 5: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? 0 : 1; break;
-    case 6: n = 1; i = unpack ? nx + 1 : nx; j = unpack ? ny + 1 : ny; break;
-    default: n = 1; i = unpack ? 0 : 1; j = unpack ? ny + 1 : ny; break;
-  }
-  if (q >= n) return;
-  const long long e = (long long)i * L.plane + (long long)k * L.RS + jpos(L, j);
-  const long long t = (long long)q * L.nz + k;
+  long long e, t;
+  if (!halo_elem(L, dir, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, unpack, e, t)) return;
   double *__restrict__ buf = hb.b[dir];
   if (unpack) a[e] = buf[t]; else buf[t] = a[e];
+}
+
+// ---- peer-to-peer halo transport (xGMI, no host in the loop) --------------------------------------------------
+// Push: the pack kernel writes the edges straight into the NEIGHBOURS' receive buffers (fine-grained device memory
+// opened through hipIpc), every block fences at system scope, and the last block to finish raises the sequence
+// number in each neighbour's flag.  Unpack: a block spins (bounded) on the LOCAL flag of its direction, then copies
+// the received edge into the halo.  Receive buffers alternate by the parity of the per-level sequence number:
+// a rank cannot push exchange n+2 before it has unpacked n+1, which its neighbour pushed after unpacking n.
+struct HaloP2P {
+  unsigned long long *flag[8];  // push: the neighbour's flag to raise; unpack: the local flag to wait on
+  unsigned long long seq;
+  unsigned int *counter;        // blocks-done counter of the push launch (device memory, left at 0)
+  int *err;                     // host-mapped error word: 1 = a wait timed out
+};
+__global__ void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
+  const int dir = blockIdx.z;
+  if (hb.present[dir]) {
+    long long e, t;
+    if (halo_elem(L, dir, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, 0, e, t)) hb.b[dir][t] = a[e];
+  }
+  __threadfence_system();  // this thread's remote writes are performed before the block reports in
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+    if (__hip_atomic_fetch_add(pp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+      __hip_atomic_store(pp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int d = 0; d < 8; d++)
+        if (hb.present[d]) __hip_atomic_store(pp.flag[d], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+__global__ void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
+  const int dir = blockIdx.z;
+  if (!hb.present[dir]) return;
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    ok = 0;
+    const long long t0 = wall_clock64();
+    while (true) {
+      if (__hip_atomic_load(pp.flag[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= pp.seq) { ok = 1; break; }
+      if (wall_clock64() - t0 > 500000000LL) break;  // 5 s of the 100 MHz constant clock: the neighbour is gone
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  if (!ok) { if (threadIdx.x == 0) *pp.err = 1; return; }
+  __threadfence_system();
+  long long e, t;
+  if (!halo_elem(L, dir, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, 1, e, t)) return;
+  a[e] = __builtin_nontemporal_load(hb.b[dir] + t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1073,9 +1108,15 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
   const int n = L->nx > L->ny ? L->nx : L->ny;
   hipLaunchKernelGGL(k_halo_pack_all, dim3((n + 63) / 64, L->nz, 8), dim3(64), 0, st, *L, a, hb, unpack);
 }
-void mgxk_halo_pack(hipStream_t st, const LevView *L, double *a, double *buf, int dir, int unpack) {
-  const int n = (dir == 0 || dir == 2) ? L->nx : ((dir == 1 || dir == 3) ? L->ny : 1);
-  hipLaunchKernelGGL(k_halo_pack, dim3((n + 63) / 64, L->nz), dim3(64), 0, st, *L, a, buf, dir, unpack);
+void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *bufs, unsigned long long *const *flags, const int *present,
+                   unsigned long long seq, unsigned int *counter, int *err, int unpack) {
+  HaloBufs hb; HaloP2P pp;
+  for (int d = 0; d < 8; d++) { hb.b[d] = bufs[d]; hb.present[d] = present[d]; pp.flag[d] = flags[d]; }
+  pp.seq = seq; pp.counter = counter; pp.err = err;
+  const int n = L->nx > L->ny ? L->nx : L->ny;
+  const dim3 grid((n + 63) / 64, L->nz, 8);
+  if (unpack) hipLaunchKernelGGL(k_halo_wait_unpack, grid, dim3(64), 0, st, *L, a, hb, pp);
+  else hipLaunchKernelGGL(k_halo_push, grid, dim3(64), 0, st, *L, a, hb, pp);
 }
 void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);

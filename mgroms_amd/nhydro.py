@@ -65,6 +65,8 @@ def nhydro_init(nx, ny, nz, npxg=1, npyg=1, rank=0, params=None, comm=None):
         comm.install()
     check(lib().mgx_init(nx, ny, nz, npxg, npyg, rank, None if params is None else C.byref(params)))
     _state["dims"] = (nx, ny, nz)
+    if comm is not None and comm.p2p and npxg * npyg > 1:
+        comm.connect_p2p()
 
 
 def nhydro_matrices(dx, dy, zeta, h, rmask=None, hc=0.0, theta_b=0.0, theta_s=0.0):
@@ -234,4 +236,6 @@ def time_residual(lev, reps):
 def counters():
     out = (C.c_longlong * 4)()
     check(lib().mgx_counters(out))
-    return dict(zip(("launches", "halo_fills", "exchanges", "allreduces"), list(out)))
+    d = dict(zip(("launches", "halo_fills", "exchanges", "allreduces"), list(out)))
+    d["p2p_exchanges"] = int(lib().mgx_p2p_exchanges())
+    return d

@@ -5,6 +5,10 @@ transport is torch.distributed -- backend "nccl" is RCCL over xGMI on ROCm.
   exchange  <- fill_halo_*: 8-neighbour non-blocking send/recv  (mg_mpi_exchange.f90:504-718)
                one batched group of isend/irecv per halo fill (ncclGroupStart/End underneath): on the fully
                connected xGMI fabric every neighbour is one hop, all edges of a fill travel concurrently.
+               With `p2p=True` (default on GPUs) the p/b/r halos of the cycle do not come through this callback at
+               all: after nhydro_init the ranks swap hipIpc handles once (connect_p2p) and libmgx.so pushes edges
+               straight into the neighbours' buffers over xGMI, flag-synchronised on the device (include/mgx.h,
+               "peer-to-peer halo transport").  The callback then only serves the set-up halos.
   allreduce <- global_sum: 1 double                             (mg_mpi_exchange.f90:1555-1571)
   allgather <- gather_3D on the 2x2 / 2x1 colour groups         (mg_gather.f90:126, mg_grids.f90:702-718)
                done with point-to-point messages inside the group (<= 4 members): no sub-communicator needed.
@@ -30,10 +34,12 @@ class _DevPtr:
 
 
 class Comm:
-    def __init__(self, device="cuda", group=None):
+    def __init__(self, device="cuda", group=None, p2p=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.device = device
+        self.p2p = (device == "cuda") if p2p is None else bool(p2p)  # device-to-device halo pushes (one node)
+        self.p2p_active = False
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -144,6 +150,30 @@ class Comm:
         check(lib().mgx_set_comm(self._ex, self._ar, self._ag, None))
         if self.device == "cuda":
             check(lib().mgx_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+    def connect_p2p(self):
+        """Collective, after mgx_init: swap the hipIpc handles of the receive slabs and open the neighbours' ones."""
+        from ._lib import check, lib
+        L = lib()
+        nb = L.mgx_p2p_handle_bytes()
+        blob = C.create_string_buffer(nb)
+        check(L.mgx_p2p_prepare(blob))
+        mine = torch.frombuffer(bytearray(blob.raw), dtype=torch.uint8).clone()
+        if not self.staged:
+            mine = mine.cuda()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        allh = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
+        check(L.mgx_p2p_connect(allh, self.world))
+        dist.barrier(group=self.group)
+        self.p2p_active = True
+
+    def set_p2p(self, on):
+        """Switch between the peer-to-peer transport and the exchange callback (all ranks together)."""
+        from ._lib import check, lib
+        check(lib().mgx_set_option(b"p2p", 1 if on else 0))
+        self.p2p_active = bool(on)
 
 
 def process_grid(world):

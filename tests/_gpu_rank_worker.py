@@ -13,7 +13,9 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, npx, npy, port, nx, ny, nz, nsmall = (int(a) for a in sys.argv[1:10])
     method = sys.argv[10]
-    bmask = len(sys.argv) > 11 and sys.argv[11] == "bmask"
+    opt = sys.argv[11] if len(sys.argv) > 11 else ""
+    bmask = opt == "bmask"
+    p2p = opt != "nop2p"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -25,7 +27,7 @@ def main():
     from oracle.mgoracle import make_seamount, seamount_geometry
 
     nhydro.set_verbose(0)
-    comm = Comm(device="cuda")
+    comm = Comm(device="cuda", p2p=p2p)
     par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6, bmask=1 if bmask else 0)
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
@@ -66,7 +68,16 @@ def main():
         assert abs(rres - rres_o) <= 1e-12 * rres_o
         assert np.array_equal(mg.grid(1).r, o.field("r", 1, rank)), rank
     c = nhydro.counters()
-    assert c["exchanges"] > 0 and c["allreduces"] > 0
+    assert c["exchanges"] > 0 and c["allreduces"] > 0  # the set-up halos always use the callback
+    assert (c["p2p_exchanges"] > 0) == p2p
+    if p2p and method == "FC":
+        # same solve through the other transport (exchange callback): the iterates must not depend on it
+        p_first = mg.grid(1).p
+        comm.set_p2p(False)
+        n2, hist2 = mg.solve_p(1e-9, 3)
+        assert n2 == n and np.array_equal(hist2, hist) and np.array_equal(mg.grid(1).p, p_first)
+        assert nhydro.counters()["p2p_exchanges"] == c["p2p_exchanges"]
+        comm.set_p2p(True)
     mg.nhydro_clean()
     dist.barrier()
     dist.destroy_process_group()

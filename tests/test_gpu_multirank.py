@@ -1,5 +1,7 @@
-"""Multi-rank solves on the GPU: (i,j) decomposition, halo exchange, norm all-reduce and coarse-level gather/split,
-each rank checked bit for bit against the oracle's emulated MPI ranks (four-colour ordering).  Ranks share the one
+"""Multi-rank solves on the GPU: (i,j) decomposition, halo exchange (peer-to-peer pushes through hipIpc-shared device
+memory by default, the torch.distributed callback in one case and in the transport cross-check of every FC case), norm
+all-reduce and coarse-level gather/split, each rank checked bit for bit against the oracle's emulated MPI ranks
+(four-colour ordering).  Ranks share the one
 GPU of the test box (<= 4 ranks + this process)."""
 import os
 import socket
@@ -27,6 +29,7 @@ def _free_port():
     (2, 2, 32, 32, 16, 32, "FC"),   # nsmall=32: gathered from level 2 on (every coarse level runs redundantly)
     (4, 1, 16, 32, 8, 16, "FC"),    # 4x1 with nsmall=16: two consecutive gathers (4 -> 2 -> 1 ranks), as bench.py uses for N>1
     (2, 1, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
+    (2, 2, 32, 32, 16, 8, "FC+nop2p"), # the exchange callback (torch.distributed) instead of the peer-to-peer pushes
     (2, 2, 16, 16, 8, 8, "FC+bmask"),  # bmask=.true.: masked coefficients + the 4-D cA halo exchange of define_matrix
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
