@@ -40,6 +40,7 @@ class Comm:
         self.device = device
         self.p2p = (device == "cuda") if p2p is None else bool(p2p)  # device-to-device halo pushes (one node)
         self.p2p_active = False
+        self.p2p_error = None
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -165,9 +166,49 @@ class Comm:
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         allh = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
-        check(L.mgx_p2p_connect(allh, self.world))
-        dist.barrier(group=self.group)
+        rc = L.mgx_p2p_connect(allh, self.world)
+        # all or nothing: one rank that cannot open a neighbour's memory sends everybody back to the callback
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cpu" if self.staged else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            self.p2p_error = L.mgx_last_error().decode() if rc else "a peer could not open the shared halo buffers"
+            L.mgx_set_option(b"p2p", 0)
+            self.p2p_active = False
+            return False
         self.p2p_active = True
+        return self._p2p_selftest()
+
+    def _p2p_selftest(self):
+        """One level-1 halo fill of a rank-coded field through both transports; the peer-to-peer one stays on only if
+        every rank got exactly the halos the callback delivers (a dead peer shows up as the 5 s device time-out)."""
+        from ._lib import MgxError, lib
+        from . import nhydro
+        L = lib()
+        g = nhydro.grid(1)
+        rng = np.random.default_rng(1000 + self.rank)
+        pat = rng.standard_normal(g._shape("p"))
+        good = 1
+        try:
+            g.set("p", pat)
+            nhydro.fill_halo(1, "p")
+            a = g.get("p")
+        except MgxError as e:
+            self.p2p_error = str(e)
+            good, a = 0, None
+        L.mgx_set_option(b"p2p", 0)
+        g.set("p", pat)
+        nhydro.fill_halo(1, "p")
+        if good and not np.array_equal(a, g.get("p")):
+            good, self.p2p_error = 0, "self-test: halos differ from the callback transport"
+        g.set("p", np.zeros_like(pat))
+        ok = torch.tensor([good], dtype=torch.int32, device="cpu" if self.staged else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        self.p2p_active = int(ok.item()) == 1
+        if self.p2p_active:
+            L.mgx_set_option(b"p2p", 1)
+        elif self.p2p_error is None:
+            self.p2p_error = "self-test failed on another rank"
+        return self.p2p_active
 
     def set_p2p(self, on):
         """Switch between the peer-to-peer transport and the exchange callback (all ranks together)."""

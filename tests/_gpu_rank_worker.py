@@ -17,10 +17,19 @@ def main():
     bmask = opt == "bmask"
     p2p = opt != "nop2p"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["OMP_NUM_THREADS"] = "1"  # every worker runs the whole emulated-MPI oracle: no OpenMP teams fighting for the cores
+    import time
+    T0 = time.time()
+    stamps = []
+
+    def stamp(what):
+        stamps.append(f"{what}={time.time() - T0:.1f}s")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
+    stamp("import_torch")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    stamp("rendezvous")
     import mgroms_amd as mg
     from mgroms_amd import nhydro
     from mgroms_amd.parallel import Comm
@@ -30,16 +39,18 @@ def main():
     comm = Comm(device="cuda", p2p=p2p)
     par = nhydro.default_params(relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6, bmask=1 if bmask else 0)
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
+    stamp("init")
     dx, dy, zeta, h = seamount_geometry(nx, ny, npx, npy, rank)
     from mgroms_amd.testcases import island_mask
     rmask = island_mask(nx, ny, npx, npy, rank) if bmask else None
     mg.nhydro_matrices(dx, dy, zeta, h, rmask, 4e3, 0.0, 0.0)
     u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
     nhydro.compute_rhs(u, v, w)
-    import time
+    stamp("matrices_rhs")
     t0 = time.time()
     n, hist = mg.solve_p(1e-9, 3)
     t_solve = time.time() - t0
+    stamp("solve")
 
     o = make_seamount(nx, ny, nz, npx, npy, relax_method=method, solver_prec=1e-9, nsmall=nsmall, ns_coarsest=6, bmask=bmask)
     if bmask:  # masked coefficients: rebuild the oracle's matrices with every rank's mask in place
@@ -48,6 +59,7 @@ def main():
         o.matrices(4e3, 0.0, 0.0)
     o.compute_rhs()
     no, ho, _ = o.solve_p(1e-9, 3)
+    stamp("oracle")
     assert mg.nlevs() == o.nlevs
     gathered = [l for l in range(1, o.nlevs + 1) if o.level_info(l, rank)["gather"]]
     for lev in range(1, o.nlevs + 1):
@@ -78,10 +90,12 @@ def main():
         assert n2 == n and np.array_equal(hist2, hist) and np.array_equal(mg.grid(1).p, p_first)
         assert nhydro.counters()["p2p_exchanges"] == c["p2p_exchanges"]
         comm.set_p2p(True)
+    stamp("checks")
     mg.nhydro_clean()
     dist.barrier()
     dist.destroy_process_group()
-    print(f"rank {rank} ok nite={n} gathered_levels={gathered} exchanges={c['exchanges']} solve_s={t_solve:.1f}")
+    stamp("teardown")
+    print(f"rank {rank} ok nite={n} gathered_levels={gathered} exchanges={c['exchanges']} solve_s={t_solve:.1f} " + " ".join(stamps))
 
 
 if __name__ == "__main__":
