@@ -43,6 +43,10 @@ void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, in
 void mgxk_gather_place(hipStream_t, const LevView *, double *, const double *, int, int, int, int);
 void mgxk_block_to_ref(hipStream_t, const LevView *, const double *, double *);
 void mgxk_split(hipStream_t, const LevView *, const LevView *, const double *, double *, int, int);
+void mgxk_gather_push(hipStream_t, const LevView *, const double *, double *const *, unsigned long long *const *, int, int, unsigned long long,
+                      unsigned int *, int *);
+void mgxk_gather_place_wait(hipStream_t, const LevView *, double *, const double *, int, int, int, int, unsigned long long *, unsigned long long,
+                            int *);
 void mgxs_coarsen2d(hipStream_t, const double *, double *, int, int, int, double);
 void mgxs_rect(hipStream_t, double *, double *, const RectOp *);
 void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
@@ -73,6 +77,8 @@ struct Level {
   bool r_halo_stale = false, b_halo_stale = false;  // deferred neighbour exchanges (multi-rank)
   size_t p2p_off[8][2];         // doubles into the receive slab: direction x parity
   unsigned long long p2p_seq = 0;  // exchanges done on this level through the peer-to-peer transport
+  size_t p2p_goff[2];           // gathered levels: ngroup blocks of the peer-to-peer gather, by parity
+  unsigned long long p2p_gseq = 0;
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
 };
 
@@ -436,12 +442,32 @@ int fine2coarse(int lev) {
     mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc); S.n_launch++;
   } else {
     mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none); S.n_launch++;
-    mgxk_block_to_ref(S.stream, &C.vs, C.vs.b, C.blk); S.n_launch++;
     const int Ng = C.nz * (C.vs.ny + 2) * (C.vs.nx + 2);
-    if (!S.ag) return fail("a gather is needed but mgx_set_comm was not called");
-    if (S.ag(S.ctx, C.group, C.ngroup, C.blk, C.gbuf, Ng)) return fail("allgather callback failed");
-    for (int q = 0; q < C.ngroup; q++) {
-      mgxk_gather_place(S.stream, &C.v, C.v.b, C.gbuf + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx); S.n_launch++;
+    if (S.p2p_on) {  // gather_3D (mg_gather.f90:95-174) as pushes into the members' gather buffers
+      const unsigned long long seq = ++C.p2p_gseq;
+      const int par = (int)(seq & 1), li = lev;
+      int me = -1;
+      for (int q = 0; q < C.ngroup; q++) if (C.group[q] == S.rank) me = q;
+      if (me < 0) return fail("gather: rank %d is not in its own group on level %d", S.rank, lev + 1);
+      double *dst[4]; unsigned long long *rflag[4];
+      for (int q = 0; q < C.ngroup; q++) {
+        dst[q] = S.peer_slab[C.group[q]] + C.p2p_goff[par] + (size_t)me * Ng;
+        rflag[q] = S.peer_flags[C.group[q]] + 1024 + (li * 4 + me) * 2 + par;
+      }
+      mgxk_gather_push(S.stream, &C.vs, C.vs.b, dst, rflag, C.ngroup, me, seq, S.p2p_counter, S.p2p_err); S.n_launch++;
+      for (int q = 0; q < C.ngroup; q++) {
+        unsigned long long *lflag = q == me ? nullptr : S.p2p_flags + 1024 + (li * 4 + q) * 2 + par;
+        mgxk_gather_place_wait(S.stream, &C.v, C.v.b, S.p2p_slab + C.p2p_goff[par] + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx, lflag, seq, S.p2p_err);
+        S.n_launch++;
+      }
+      S.n_p2p++;
+    } else {
+      mgxk_block_to_ref(S.stream, &C.vs, C.vs.b, C.blk); S.n_launch++;
+      if (!S.ag) return fail("a gather is needed but mgx_set_comm was not called");
+      if (S.ag(S.ctx, C.group, C.ngroup, C.blk, C.gbuf, Ng)) return fail("allgather callback failed");
+      for (int q = 0; q < C.ngroup; q++) {
+        mgxk_gather_place(S.stream, &C.v, C.v.b, C.gbuf + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx); S.n_launch++;
+      }
     }
   }
   // b's halo is not read by relax/residual either: physical mirrors are in place, neighbour exchange deferred
@@ -1096,6 +1122,12 @@ int mgx_p2p_prepare(void *handles_out) {
       for (int par = 0; par < 2; par++) { L.p2p_off[d][par] = off; off += (c + 31) / 32 * 32; }
       L.p2p_seq = 0;
     }
+  for (auto &L : S.lev) {
+    L.p2p_gseq = 0; L.p2p_goff[0] = L.p2p_goff[1] = 0;
+    if (!L.gather) continue;
+    const size_t Ng = (size_t)L.nz * (L.vs.ny + 2) * (L.vs.nx + 2);
+    for (int par = 0; par < 2; par++) { L.p2p_goff[par] = off; off += ((size_t)L.ngroup * Ng + 31) / 32 * 32; }
+  }
   S.p2p_slab_n = off;
   HIPCHK(hipExtMallocWithFlags((void **)&S.p2p_slab, off * sizeof(double), hipDeviceMallocFinegrained));
   HIPCHK(hipExtMallocWithFlags((void **)&S.p2p_flags, 4096 * sizeof(unsigned long long), hipDeviceMallocFinegrained));
@@ -1119,11 +1151,14 @@ int mgx_p2p_connect(const void *all_handles, int nranks) {
   NEED_INIT();
   if (!S.p2p_slab) return fail("mgx_p2p_connect: call mgx_p2p_prepare first");
   if (nranks != S.nranks) return fail("mgx_p2p_connect: %d handle sets for %d ranks", nranks, S.nranks);
-  if ((int)S.lev.size() * 16 > 4096) return fail("mgx_p2p_connect: too many levels");
+  if ((int)S.lev.size() * 16 > 1024 || (int)S.lev.size() * 8 > 3072) return fail("mgx_p2p_connect: too many levels");
   S.peer_slab.assign(nranks, nullptr); S.peer_flags.assign(nranks, nullptr);
   S.peer_slab[S.rank] = S.p2p_slab; S.peer_flags[S.rank] = S.p2p_flags;
   std::vector<char> need(nranks, 0);  // only the ranks that are a neighbour on some level are opened
-  for (auto &L : S.lev) for (int d = 0; d < 8; d++) if (L.neighb[d] >= 0) need[L.neighb[d]] = 1;
+  for (auto &L : S.lev) {
+    for (int d = 0; d < 8; d++) if (L.neighb[d] >= 0) need[L.neighb[d]] = 1;
+    if (L.gather) for (int q = 0; q < L.ngroup; q++) need[L.group[q]] = 1;
+  }
   const hipIpcMemHandle_t *h = (const hipIpcMemHandle_t *)all_handles;
   for (int r = 0; r < nranks; r++) {
     if (r == S.rank || !need[r]) continue;

@@ -894,6 +894,57 @@ __global__ void k_block_to_ref(LevView Cs, const double *__restrict__ js, double
   const int j = (int)(ji % (Cs.ny + 2)), i = (int)(ji / (Cs.ny + 2));
   blk[t] = js[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)];
 }
+// Peer-to-peer gather (same protocol as the halo pushes): my restricted block, converted to the reference layout on
+// the fly, is written into slot `me` of every group member's gather buffer (mine included); the last block raises my
+// flag at the other members.  k_gather_place_wait then waits for member q's flag before placing its block.
+struct GatherP2P { double *dst[4]; unsigned long long *flag[4]; int ng, me; unsigned long long seq; unsigned int *counter; int *err; };
+__global__ void k_gather_push(LevView Cs, const double *__restrict__ js, GatherP2P gp) {
+  const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const int k = (int)(t % Cs.nz);
+    const long long ji = t / Cs.nz;
+    const int j = (int)(ji % (Cs.ny + 2)), i = (int)(ji / (Cs.ny + 2));
+    const double v = js[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)];
+    for (int q = 0; q < gp.ng; q++) gp.dst[q][t] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(gp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      __hip_atomic_store(gp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      for (int q = 0; q < gp.ng; q++)
+        if (q != gp.me) __hip_atomic_store(gp.flag[q], gp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+__global__ void k_gather_place_wait(LevView C, double *__restrict__ dstjs, const double *__restrict__ blk, int nxc, int nyc, int l, int m,
+                                    unsigned long long *flag, unsigned long long seq, int *err) {
+  if (flag) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+      ok = 0;
+      const long long t0 = wall_clock64();
+      while (true) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) { ok = 1; break; }
+        if (wall_clock64() - t0 > 500000000LL) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    if (!ok) { if (threadIdx.x == 0) *err = 1; return; }
+    __threadfence_system();
+  }
+  const long long n = (long long)C.nz * nyc * nxc;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = (int)(t % C.nz);
+  const long long ji = t / C.nz;
+  const int j = 1 + (int)(ji % nyc), i = 1 + (int)(ji / nyc);
+  const double v = __builtin_nontemporal_load(blk + ((long long)i * (nyc + 2) + j) * C.nz + k);
+  dstjs[(long long)(i + l * nxc) * C.plane + (long long)k * C.RS + jpos(C, j + m * nyc)] = v;
+}
 // split (mg_gather.f90:177-220): own quadrant of the gathered p, halo included, into the small JS block
 __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, double *__restrict__ dst, int l, int m) {
   const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
@@ -1129,6 +1180,19 @@ void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const do
 void mgxk_block_to_ref(hipStream_t st, const LevView *Cs, const double *js, double *blk) {
   const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
   hipLaunchKernelGGL(k_block_to_ref, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *Cs, js, blk);
+}
+void mgxk_gather_push(hipStream_t st, const LevView *Cs, const double *js, double *const *dst, unsigned long long *const *flags, int ng, int me,
+                      unsigned long long seq, unsigned int *counter, int *err) {
+  GatherP2P gp;
+  for (int q = 0; q < 4; q++) { gp.dst[q] = q < ng ? dst[q] : nullptr; gp.flag[q] = q < ng ? flags[q] : nullptr; }
+  gp.ng = ng; gp.me = me; gp.seq = seq; gp.counter = counter; gp.err = err;
+  const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
+  hipLaunchKernelGGL(k_gather_push, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *Cs, js, gp);
+}
+void mgxk_gather_place_wait(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m,
+                            unsigned long long *flag, unsigned long long seq, int *err) {
+  const long long n = (long long)C->nz * nyc * nxc;
+  hipLaunchKernelGGL(k_gather_place_wait, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *C, dstjs, blk, nxc, nyc, l, m, flag, seq, err);
 }
 void mgxk_split(hipStream_t st, const LevView *C, const LevView *Cs, const double *pc, double *dst, int l, int m) {
   const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
