@@ -53,11 +53,16 @@ void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
 void mgxs_define_matrix(hipStream_t, const GeoView *, int lev1, int phase);
 void mgxs_pivots(hipStream_t, const LevView *);
 void mgxs_slopes_js(hipStream_t, const GeoView *, const LevView *);
-void mgxs_rhs_uf(hipStream_t, const GeoView *, const ModelView *, double *);
-void mgxs_rhs_vf(hipStream_t, const GeoView *, const ModelView *, double *);
-void mgxs_rhs_wf(hipStream_t, const GeoView *, const ModelView *, double *);
-void mgxs_rhs_accum(hipStream_t, const GeoView *, const LevView *, const double *, int);
-void mgxs_correct_uvw(hipStream_t, const GeoView *, const LevView *, const ModelView *);
+void mgxm_ref2model(hipStream_t, const double *, double *, int rows, int nh, int nx, int ny);
+void mgxm_ref2model_2d(hipStream_t, const double *, double *, int nx, int ny);
+void mgxm_js_model(hipStream_t, const LevView *, double *js, double *md, int dir);
+void mgxm_rhs_uf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxm_rhs_vf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxm_rhs_wf(hipStream_t, const GeoView *, const ModelView *, double *);
+void mgxm_flux_zero_face(hipStream_t, const GeoView *, double *, int face, int pl);
+void mgxm_flux_face_copy(hipStream_t, const GeoView *, double *, double *, int face, int pl, int unpack);
+void mgxm_rhs_accum(hipStream_t, const GeoView *, double *, const double *, int);
+void mgxm_correct_uvw(hipStream_t, const GeoView *, const double *, const ModelView *);
 }
 
 namespace {
@@ -104,7 +109,7 @@ struct State {
   unsigned int *p2p_counter = nullptr;
   int *p2p_err = nullptr;   // host-mapped
   long long n_p2p = 0;
-  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_fz = nullptr;
+  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
   std::vector<void *> allocs;
   int verbose = 1;
   int warm_start = 0;   // keep p between solves instead of the reference's cold start (mg_solvers.f90:35)
@@ -618,6 +623,17 @@ int define_matrices() {
     mgxs_define_matrix(S.stream, &L.g, l == 0, 0); S.n_launch += 2;
     if (S.par.bmask) CHK(rl_fill_halo(L, L.g.cA, 8 * L.nz, 1, 0, true));  // fill_halo(lev,cA), mg_define_matrix.f90:611-613
     mgxs_define_matrix(S.stream, &L.g, l == 0, 1); S.n_launch++;
+    if (l == 0) {  // i-fastest copies for compute_rhs / correct_uvw (mgx_model.hip)
+      mgxm_ref2model(S.stream, L.g.zw, L.g.mzw, L.nz + 1, 2, L.nx, L.ny);
+      mgxm_ref2model(S.stream, L.g.dzw, L.g.mdzw, L.nz + 1, 1, L.nx, L.ny);
+      mgxm_ref2model(S.stream, L.g.cw, L.g.mcw, L.nz + 1, 1, L.nx, L.ny);
+      mgxm_ref2model(S.stream, L.g.zxdy, L.g.mzxdy, L.nz, 1, L.nx, L.ny);
+      mgxm_ref2model(S.stream, L.g.zydx, L.g.mzydx, L.nz, 1, L.nx, L.ny);
+      mgxm_ref2model_2d(S.stream, L.g.dx, L.g.mdx, L.nx, L.ny);
+      mgxm_ref2model_2d(S.stream, L.g.dy, L.g.mdy, L.nx, L.ny);
+      mgxm_ref2model_2d(S.stream, L.g.rmask, L.g.mrmask, L.nx, L.ny);
+      S.n_launch += 8;
+    }
     for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
@@ -630,7 +646,27 @@ int define_matrices() {
 }
 
 // the model fields + the level-1 mask (only read when bmask)
-ModelView model_view() { return ModelView{S.d_u, S.d_v, S.d_w, S.par.bmask ? S.lev[0].g.rmask : nullptr, S.par.bmask ? 1 : 0}; }
+ModelView model_view() { return ModelView{S.d_u, S.d_v, S.d_w, S.par.bmask ? S.lev[0].g.mrmask : nullptr, S.par.bmask ? 1 : 0}; }
+
+// fill_halo(1,uf,lbc_null='u') / fill_halo(1,vf,lbc_null='v') (mg_compute_rhs.f90:171,272), reduced to the entries the
+// divergence reads: the first and last face.  Physical side: zero flux.  Neighbour: my last face is the neighbour's first
+// face, computed over there from its own copy of the shared velocity (the reference takes that value too).
+int flux_halo(Level &L, int face) {
+  const int lo = face == 0 ? L.neighb[3] : L.neighb[0], hi = face == 0 ? L.neighb[1] : L.neighb[2];  // W,E or S,N
+  const int last = face == 0 ? L.nx + 1 : L.ny + 1, cnt = L.nz * (face == 0 ? L.ny : L.nx);
+  if (lo < 0) { mgxm_flux_zero_face(S.stream, &L.g, S.d_fx, face, 1); S.n_launch++; }
+  if (hi < 0) { mgxm_flux_zero_face(S.stream, &L.g, S.d_fx, face, last); S.n_launch++; }
+  if (lo < 0 && hi < 0) return 0;
+  if ((size_t)cnt > S.xbuf_n) return fail("halo buffer too small");
+  // the exchange callback moves equal counts both ways with every peer: the unused direction carries a zero buffer
+  int n = 0, peer[2], cn[2]; double *sb[2], *rb[2];
+  if (lo >= 0) { mgxm_flux_face_copy(S.stream, &L.g, S.d_fx, S.xbuf[0], face, 1, 0); S.n_launch++; peer[n] = lo; cn[n] = cnt; sb[n] = S.xbuf[0]; rb[n] = S.xbuf[8]; n++; }
+  if (hi >= 0) { peer[n] = hi; cn[n] = cnt; sb[n] = S.xbuf[2]; rb[n] = S.xbuf[9]; n++; }
+  if (hi >= 0) HIPCHK(hipMemsetAsync(S.xbuf[2], 0, (size_t)cnt * sizeof(double), S.stream));
+  CHK(exchange(n, peer, sb, rb, cn));
+  if (hi >= 0) { mgxm_flux_face_copy(S.stream, &L.g, S.d_fx, S.xbuf[9], face, last, 1); S.n_launch++; }
+  return 0;
+}
 
 // mg_compute_rhs.f90:14-379 on the device copies of u,v,w
 int compute_rhs_dev() {
@@ -638,14 +674,25 @@ int compute_rhs_dev() {
   TicScope ts(1, "compute_rhs");  // nhydro.f90:81
   ModelView M = model_view();
   HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));
-  mgxs_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  if (!S.par.bmask) CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'u'));  // mg_compute_rhs.f90:170-172
-  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 0); S.n_launch++;
-  mgxs_rhs_vf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  if (!S.par.bmask) CHK(rl_fill_halo(L, S.d_fx, L.nz, 1, 'v'));  // :271-273
-  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fx, 1); S.n_launch++;
-  mgxs_rhs_wf(S.stream, &L.g, &M, S.d_fz); S.n_launch++;
-  mgxs_rhs_accum(S.stream, &L.g, &L.v, S.d_fz, 2); S.n_launch++;
+  mgxm_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
+  if (!S.par.bmask) CHK(flux_halo(L, 0));  // mg_compute_rhs.f90:170-172
+  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 0); S.n_launch++;
+  mgxm_rhs_vf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
+  if (!S.par.bmask) CHK(flux_halo(L, 1));  // :271-273
+  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 1); S.n_launch++;
+  mgxm_rhs_wf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
+  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 2); S.n_launch++;
+  mgxm_js_model(S.stream, &L.v, L.v.b, S.d_bm, 1); S.n_launch++;  // interior of b in the solver's layout
+  return 0;
+}
+
+// mg_correct_uvw.f90:15-115 on the device copies of u,v,w
+int correct_uvw_dev() {
+  Level &L = S.lev[0];
+  TicScope ts(1, "correct_uvw");
+  ModelView M = model_view();
+  mgxm_js_model(S.stream, &L.v, L.v.p, S.d_bm, 0); S.n_launch++;
+  mgxm_correct_uvw(S.stream, &L.g, S.d_bm, &M); S.n_launch++;
   return 0;
 }
 
@@ -830,7 +877,13 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     CHK(dmalloc(&L.g.zw, (size_t)(L.ny + 4) * (L.nx + 4) * (L.nz + 1)));
     CHK(dmalloc(&L.g.cw, n2 * (L.nz + 1)));
     L.g.dzw = L.g.zxdy = L.g.zydx = nullptr;
-    if (l == 0) { CHK(dmalloc(&L.g.dzw, n2 * (L.nz + 1))); CHK(dmalloc(&L.g.zxdy, n2 * L.nz)); CHK(dmalloc(&L.g.zydx, n2 * L.nz)); }
+    L.g.mzw = L.g.mdzw = L.g.mzxdy = L.g.mzydx = L.g.mcw = L.g.mdx = L.g.mdy = L.g.mrmask = nullptr;
+    if (l == 0) {
+      CHK(dmalloc(&L.g.dzw, n2 * (L.nz + 1))); CHK(dmalloc(&L.g.zxdy, n2 * L.nz)); CHK(dmalloc(&L.g.zydx, n2 * L.nz));
+      CHK(dmalloc(&L.g.mzw, n2 * (L.nz + 1))); CHK(dmalloc(&L.g.mdzw, n2 * (L.nz + 1))); CHK(dmalloc(&L.g.mcw, n2 * (L.nz + 1)));
+      CHK(dmalloc(&L.g.mzxdy, n2 * L.nz)); CHK(dmalloc(&L.g.mzydx, n2 * L.nz));
+      CHK(dmalloc(&L.g.mdx, n2)); CHK(dmalloc(&L.g.mdy, n2)); CHK(dmalloc(&L.g.mrmask, n2));
+    }
     if (L.gather) {
       const int nxc = L.nx / L.ngx, nyc = L.ny / L.ngy;
       L.vs = L.v;
@@ -861,8 +914,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_u, (size_t)(L1.nx + 1) * (L1.ny + 2) * L1.nz));
   CHK(dmalloc(&S.d_v, (size_t)(L1.nx + 2) * (L1.ny + 1) * L1.nz));
   CHK(dmalloc(&S.d_w, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
-  CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
-  CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  CHK(dmalloc(&S.d_bm, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
   CHK(sync_stream());
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
@@ -919,8 +972,7 @@ int mgx_solve(double *u, double *v, double *w, const double *rmask) {
   CHK(compute_rhs_dev());
   CHK(solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr));
   Level &L = S.lev[0];
-  ModelView M = model_view();
-  mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
+  CHK(correct_uvw_dev());
   const size_t nu = (size_t)(L.nx + 1) * (L.ny + 2) * L.nz, nv = (size_t)(L.nx + 2) * (L.ny + 1) * L.nz, nw = (size_t)(L.nx + 2) * (L.ny + 2) * (L.nz + 1);
   HIPCHK(hipMemcpyAsync(u, S.d_u, nu * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   HIPCHK(hipMemcpyAsync(v, S.d_v, nv * sizeof(double), hipMemcpyDeviceToHost, S.stream));
@@ -939,12 +991,8 @@ int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *
   S.d_u = u_dev; S.d_v = v_dev; S.d_w = w_dev;
   int rc = compute_rhs_dev();
   if (!rc) rc = solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr);
-  if (!rc) {
-    Level &L = S.lev[0];
-    ModelView M = model_view();
-    mgxs_correct_uvw(S.stream, &L.g, &L.v, &M); S.n_launch++;
-    if (hipStreamSynchronize(S.stream) != hipSuccess) rc = fail("stream synchronize failed");
-  }
+  if (!rc) rc = correct_uvw_dev();
+  if (!rc) rc = sync_stream();
   S.d_u = su; S.d_v = sv; S.d_w = sw;
   return rc;
 }

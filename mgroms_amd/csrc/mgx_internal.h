@@ -31,6 +31,7 @@ struct GeoView {
   double *cw;                  // (nz+1, 0:ny+1, 0:nx+1)
   double *cA;                  // (8, nz, 0:ny+1, 0:nx+1)   scratch shared by all levels
   double *dzw, *zxdy, *zydx;   // level 1 only
+  double *mzw, *mdzw, *mzxdy, *mzydx, *mcw, *mdx, *mdy, *mrmask;  // level 1 only: i-fastest copies read by compute_rhs / correct_uvw (mgx_model.hip)
   double *rmask;               // (0:ny+1, 0:nx+1) boundary / land mask of the level (mg_define_matrix.f90:78-79,157-161)
   int bmask;                   // namelist bmask: masked coefficients
 };

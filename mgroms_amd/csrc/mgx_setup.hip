@@ -1,6 +1,6 @@
 // Set-up kernels (run once per geometry): coarsening of the 2-D geometry, sigma-coordinate depths,
-// the 8 stored coefficients per cell, the tridiagonal pivots; plus compute_rhs / correct_uvw on the
-// model's (i,j,k)-ordered velocities.  These work in the reference (Fortran) layout; the coefficients
+// the 8 stored coefficients per cell, the tridiagonal pivots (compute_rhs / correct_uvw live in mgx_model.hip).
+// These work in the reference (Fortran) layout; the coefficients
 // are then repacked into the solver's JS layout (mgx_kernels.hip:k_convert).  One lane = one (j,i) column.
 // Operation order follows the reference line by line (compiled with -ffp-contract=off).
 #include "mgx_internal.h"
@@ -285,141 +285,6 @@ __global__ void k_pivots(LevView L) {
 // compute_rhs (mg_compute_rhs.f90:14-379, bmask = .false.) on level 1.  u,v,w are the model's
 // (i,j,k)-ordered arrays on the device; uf/vf share `fx` (nz,0:ny+1,0:nx+1), wf is `fz` (nz+1,..).
 // ------------------------------------------------------------------------------------------------
-struct ModelView { double *u, *v, *w, *rmask; int bmask; };
-#define U(i, j, k) M.u[(((long long)((k)-1)) * (ny + 2) + (j)) * (nx + 1) + ((i)-1)]
-#define V(i, j, k) M.v[(((long long)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
-#define Wv(i, j, k) M.w[(((long long)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
-#define RM(j, i) (M.rmask ? A2(M.rmask, j, i) : 1.0)
-#define UMK(j, i) (M.bmask ? (((i) >= 1) ? RM(j, (i)-1) * RM(j, i) : 0.0) : 1.0)
-#define VMK(j, i) (M.bmask ? (((j) >= 1) ? RM((j)-1, i) * RM(j, i) : 0.0) : 1.0)
-#define DZW(k, j, i) G.dzw[I3P(k, j, i)]
-#define ZXDY(k, j, i) G.zxdy[I3(k, j, i)]
-#define ZYDX(k, j, i) G.zydx[I3(k, j, i)]
-
-__global__ void k_rhs_uf(GeoView G, ModelView M, double *__restrict__ fx) {
-  COLUMN_THREAD(1, G.ny, 1, G.nx + 1)
-  const double two = 2.0, hlf = 0.5, qrt = 0.25;
-  int k = 1;
-  fx[I3(k, j, i)] =
-      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
-       - qrt * (+ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))
-       - (+ZXDY(k, j, i) * ZXDY(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
-          ZXDY(k, j, i - 1) * ZXDY(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1))) *
-             (hlf * (DX(j, i) + DX(j, i - 1))) * U(i, j, k)
-       - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-              (hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) + hlf * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i)) +
-          ZXDY(k, j, i - 1) * ZYDX(k, j, i - 1) / (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * hlf *
-              (hlf * (DY(j, i - 1) + DY(j - 1, i - 1)) * V(i - 1, j, k) * VMK(j, i - 1) +
-               hlf * (DY(j + 1, i - 1) + DY(j, i - 1)) * V(i - 1, j + 1, k) * VMK(j + 1, i - 1)))) * UMK(j, i);
-  for (k = 2; k <= nz - 1; k++)
-    fx[I3(k, j, i)] =
-        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
-         - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
-                  ZXDY(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                  ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                  ZXDY(k, j, i - 1) * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
-  k = nz;
-  fx[I3(k, j, i)] =
-      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) * (DY(j, i) + DY(j, i - 1)) * U(i, j, k)
-       - qrt * (+ZXDY(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
-                ZXDY(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                ZXDY(k, j, i - 1) * DZW(k, j, i - 1) * Wv(i - 1, j, k - 1) * RM(j, i - 1) +
-                ZXDY(k, j, i - 1) * two * DZW(k + 1, j, i - 1) * Wv(i - 1, j, k + 1 - 1) * RM(j, i - 1))) * UMK(j, i);
-}
-
-__global__ void k_rhs_vf(GeoView G, ModelView M, double *__restrict__ fx) {
-  COLUMN_THREAD(1, G.ny + 1, 1, G.nx)
-  const double two = 2.0, hlf = 0.5, qrt = 0.25;
-  int k = 1;
-  fx[I3(k, j, i)] =
-      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
-       - qrt * (+ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))
-       - (+ZYDX(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) +
-          ZYDX(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i))) *
-             hlf * (DY(j, i) + DY(j - 1, i)) * V(i, j, k)
-       - (+ZXDY(k, j, i) * ZYDX(k, j, i) / (CW(k, j, i) + CW(k + 1, j, i)) * hlf *
-              (hlf * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) + hlf * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1)) +
-          ZXDY(k, j - 1, i) * ZYDX(k, j - 1, i) / (CW(k, j - 1, i) + CW(k + 1, j - 1, i)) * hlf *
-              (hlf * (DX(j - 1, i) + DX(j - 1, i - 1)) * U(i, j - 1, k) * UMK(j - 1, i) +
-               hlf * (DX(j - 1, i + 1) + DX(j - 1, i)) * U(i + 1, j - 1, k) * UMK(j - 1, i + 1)))) * VMK(j, i);
-  for (k = 2; k <= nz - 1; k++)
-    fx[I3(k, j, i)] =
-        (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
-         - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
-                  ZYDX(k, j, i) * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                  ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                  ZYDX(k, j - 1, i) * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
-  k = nz;
-  fx[I3(k, j, i)] =
-      (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) * (DX(j, i) + DX(j - 1, i)) * V(i, j, k)
-       - qrt * (+ZYDX(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) * RM(j, i) +
-                ZYDX(k, j, i) * two * DZW(k + 1, j, i) * Wv(i, j, k + 1 - 1) * RM(j, i) +
-                ZYDX(k, j - 1, i) * DZW(k, j - 1, i) * Wv(i, j - 1, k - 1) * RM(j - 1, i) +
-                ZYDX(k, j - 1, i) * two * DZW(k + 1, j - 1, i) * Wv(i, j - 1, k + 1 - 1) * RM(j - 1, i))) * VMK(j, i);
-}
-
-__global__ void k_rhs_wf(GeoView G, ModelView M, double *__restrict__ fz) {
-  COLUMN_THREAD(1, G.ny, 1, G.nx)
-  const double hlf = 0.5, qrt = 0.25;
-  fz[I3P(1, j, i)] = 0.0;
-  for (int k = 2; k <= nz; k++) {
-    double t = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-               qrt * hlf * (+ZXDY(k, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k) * UMK(j, i) +
-                            ZXDY(k, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k) * UMK(j, i + 1) +
-                            ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
-                            ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1));
-    t = t - qrt * hlf * (+ZYDX(k, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k) * VMK(j, i) +
-                         ZYDX(k, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k) * VMK(j + 1, i) +
-                         ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
-                         ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
-    fz[I3P(k, j, i)] = t;
-  }
-  const int k = nz + 1;
-  fz[I3P(k, j, i)] = CW(k, j, i) * DZW(k, j, i) * Wv(i, j, k - 1) -
-                     hlf * hlf * (+ZXDY(k - 1, j, i) * (DX(j, i) + DX(j, i - 1)) * U(i, j, k - 1) * UMK(j, i) +
-                                  ZXDY(k - 1, j, i) * (DX(j, i + 1) + DX(j, i)) * U(i + 1, j, k - 1) * UMK(j, i + 1)) -
-                     hlf * hlf * (+ZYDX(k - 1, j, i) * (DY(j, i) + DY(j - 1, i)) * V(i, j, k - 1) * VMK(j, i) +
-                                  ZYDX(k - 1, j, i) * (DY(j + 1, i) + DY(j, i)) * V(i, j + 1, k - 1) * VMK(j + 1, i));
-}
-
-// rhs accumulation into the JS field b of level 1: mode 0: b = fx(i+1)-fx(i) ; 1: b += fx(j+1)-fx(j) ; 2: b += fz(k+1)-fz(k)
-__global__ void k_rhs_accum(GeoView G, LevView L, const double *__restrict__ f, int mode) {
-  COLUMN_THREAD(1, G.ny, 1, G.nx)
-  const long long o = (long long)i * L.plane + jpos(L, j);
-  for (int k = 1; k <= nz; k++) {
-    const long long e = o + (long long)(k - 1) * L.RS;
-    if (mode == 0) L.b[e] = f[I3(k, j, i + 1)] - f[I3(k, j, i)];
-    else if (mode == 1) L.b[e] = L.b[e] + f[I3(k, j + 1, i)] - f[I3(k, j, i)];
-    else L.b[e] = L.b[e] + f[I3P(k + 1, j, i)] - f[I3P(k, j, i)];
-  }
-}
-
-// correct_uvw (mg_correct_uvw.f90:73-108); p is read from the JS field of level 1
-__global__ void k_correct_uvw(GeoView G, LevView L, ModelView M) {
-  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
-  const double one = 1.0, hlf = 0.5;
-  const double *__restrict__ p = L.p;
-#define PJS(k, jj, ii) p[(long long)(ii)*L.plane + (long long)((k)-1) * L.RS + jpos(L, jj)]
-  if (i >= 1) {
-    const double dxu = hlf * (DX(j, i) + DX(j, i - 1));
-    for (int k = 1; k <= nz; k++) U(i, j, k) = U(i, j, k) - one / dxu * (PJS(k, j, i) - PJS(k, j, i - 1)) * UMK(j, i);
-  }
-  if (j >= 1) {
-    const double dyv = hlf * (DY(j, i) + DY(j - 1, i));
-    for (int k = 1; k <= nz; k++) V(i, j, k) = V(i, j, k) - one / dyv * (PJS(k, j, i) - PJS(k, j - 1, i)) * VMK(j, i);
-  }
-  for (int k = 2; k <= nz; k++) {
-    const double dzw = ZR(k, j, i) - ZR(k - 1, j, i);
-    Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (PJS(k, j, i) - PJS(k - 1, j, i));
-  }
-  const int k = nz + 1;
-  const double dzw = ZW(nz + 1, j, i) - ZR(nz, j, i);
-  Wv(i, j, k - 1) = Wv(i, j, k - 1) - one / dzw * (-PJS(k - 1, j, i));
-#undef PJS
-}
-
 // ------------------------------------------------------------------------------------------------
 static inline dim3 cgrid(int nj, int ni) { return dim3((nj + 63) / 64, (ni + 3) / 4); }
 static const dim3 CBLK(64, 4);
@@ -446,9 +311,4 @@ void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
 }
 void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
-void mgxs_rhs_uf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_uf, cgrid(G->ny, G->nx + 1), CBLK, 0, st, *G, *M, fx); }
-void mgxs_rhs_vf(hipStream_t st, const GeoView *G, const ModelView *M, double *fx) { hipLaunchKernelGGL(k_rhs_vf, cgrid(G->ny + 1, G->nx), CBLK, 0, st, *G, *M, fx); }
-void mgxs_rhs_wf(hipStream_t st, const GeoView *G, const ModelView *M, double *fz) { hipLaunchKernelGGL(k_rhs_wf, cgrid(G->ny, G->nx), CBLK, 0, st, *G, *M, fz); }
-void mgxs_rhs_accum(hipStream_t st, const GeoView *G, const LevView *L, const double *f, int mode) { hipLaunchKernelGGL(k_rhs_accum, cgrid(G->ny, G->nx), CBLK, 0, st, *G, *L, f, mode); }
-void mgxs_correct_uvw(hipStream_t st, const GeoView *G, const LevView *L, const ModelView *M) { hipLaunchKernelGGL(k_correct_uvw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L, *M); }
 }
