@@ -40,6 +40,7 @@ void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, unsi
                    unsigned int *, int *, int);
 void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
+void mgxk_convert8(hipStream_t, const LevView *, const double *);
 void mgxk_gather_place(hipStream_t, const LevView *, double *, const double *, int, int, int, int);
 void mgxk_block_to_ref(hipStream_t, const LevView *, const double *, double *);
 void mgxk_split(hipStream_t, const LevView *, const LevView *, const double *, double *, int, int);
@@ -634,7 +635,8 @@ int define_matrices() {
       mgxm_ref2model_2d(S.stream, L.g.rmask, L.g.mrmask, L.nx, L.ny);
       S.n_launch += 8;
     }
-    for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
+    if (L.nz <= 128) { mgxk_convert8(S.stream, &L.v, L.g.cA); S.n_launch++; }  // 16 columns x nz x 8 slots in LDS (<= 131 KB)
+    else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;

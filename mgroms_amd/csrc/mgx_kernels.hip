@@ -872,6 +872,26 @@ __global__ void k_convert(LevView L, double *__restrict__ js, double *__restrict
   if (dir == 0) js[e] = ref[t * nslot + slot]; else ref[t * nslot + slot] = js[e];
 }
 
+// all 8 coefficient slots ref -> JS in one pass: a block takes TJ=16 consecutive columns of one plane, i.e. one contiguous
+// run of 16*nz*8 doubles of cA(8,k,j,i), stages it in LDS (column stride padded by one double) and writes every slot
+// row as 8 even-j + 8 odd-j neighbours (two 64-byte runs).
+struct Slots8 { double *s[8]; };
+__global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const double *__restrict__ ref) {
+  extern __shared__ double lds[];
+  constexpr int TJ = 16;
+  const int nz = L.nz, cs = nz * 8 + 1;
+  const int i = blockIdx.y, j0 = blockIdx.x * TJ;
+  const int nj = min(TJ, L.ny + 2 - j0);
+  const double *__restrict__ src = ref + ((long long)i * (L.ny + 2) + j0) * nz * 8;
+  const int n = nj * nz * 8;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) lds[(t / (nz * 8)) * cs + t % (nz * 8)] = src[t];
+  __syncthreads();
+  for (int t = threadIdx.x; t < TJ * nz * 8; t += blockDim.x) {
+    const int jl = t % TJ, k = (t / TJ) % nz, sl = t / (TJ * nz);
+    if (jl < nj) out.s[sl][(long long)i * L.plane + (long long)k * L.RS + jpos(L, j0 + jl)] = lds[jl * cs + k * 8 + sl];
+  }
+}
+
 // gather (mg_gather.f90:95-174): copy the interior of member block (l,m) (reference layout incl. halo, as received)
 // into the JS coarse b at offset (l*nxc, m*nyc)
 __global__ void k_gather_place(LevView C, double *__restrict__ dstjs, const double *__restrict__ blk, int nxc, int nyc, int l, int m) {
@@ -1172,6 +1192,13 @@ void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *b
 void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
   hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *L, js, ref, nslot, slot, dir);
+}
+void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {
+  Slots8 o;
+  for (int q = 0; q < 8; q++) o.s[q] = L->cA[q];
+  const size_t lds = (size_t)16 * (L->nz * 8 + 1) * sizeof(double);
+  (void)hipFuncSetAttribute((const void *)k_convert8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  // > 64 KB from nz = 64 on
+  hipLaunchKernelGGL(k_convert8, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
 }
 void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m) {
   const long long n = (long long)C->nz * nyc * nxc;

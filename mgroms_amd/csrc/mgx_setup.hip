@@ -27,6 +27,19 @@
   const int nx = G.nx, ny = G.ny, nz = G.nz;                                  \
   (void)nx; (void)ny; (void)nz;
 
+// k-parallel variant for the coefficient kernels: lanes run along k, the fastest index of the reference layout, so a
+// wave reads and writes whole k-runs of a column (cA: 64 contiguous bytes per lane).  nk = rows handled per column.
+#define KCOL_THREAD(nk, jlo, jhi, ilo, ihi)                                   \
+  const int nx = G.nx, ny = G.ny, nz = G.nz;                                  \
+  (void)nx; (void)ny; (void)nz;                                               \
+  const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
+  const int k = 1 + (int)(t_ % (nk));                                         \
+  const long long c_ = t_ / (nk);                                             \
+  const int nj_ = (jhi) - (jlo) + 1;                                          \
+  const int j = (jlo) + (int)(c_ % nj_);                                      \
+  const int i = (ilo) + (int)(c_ / nj_);                                      \
+  if (i > (ihi)) return;
+
 // mg_define_matrix.f90:116-138: dx,dy = 1/2 sum4 ; zeta,h = 1/4 sum4.  dst is (0:nyc+1,0:nxc+1)
 __global__ void k_coarsen2d(const double *__restrict__ src, double *__restrict__ dst, int nyf, int nyc, int nxc, double fac) {
   const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -91,35 +104,33 @@ __global__ void k_zr_zw(GeoView G, double hlim, double theta_b, double theta_s) 
 
 // mg_define_matrix.f90:283-336: dzw, zxdy, zydx (level 1) and cw, on 0:n+1
 __global__ void k_cw(GeoView G, int lev1) {
-  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  KCOL_THREAD(G.nz + 1, 0, G.ny + 1, 0, G.nx + 1)
   const double one = 1.0, hlf = 0.5;
   if (lev1) {
-    G.dzw[I3P(1, j, i)] = ZR(1, j, i) - ZW(1, j, i);
-    for (int k = 2; k <= nz; k++) G.dzw[I3P(k, j, i)] = ZR(k, j, i) - ZR(k - 1, j, i);
-    G.dzw[I3P(nz + 1, j, i)] = ZW(nz + 1, j, i) - ZR(nz, j, i);
-    for (int k = 1; k <= nz; k++) {
+    if (k == 1) G.dzw[I3P(1, j, i)] = ZR(1, j, i) - ZW(1, j, i);
+    else if (k <= nz) G.dzw[I3P(k, j, i)] = ZR(k, j, i) - ZR(k - 1, j, i);
+    else G.dzw[I3P(nz + 1, j, i)] = ZW(nz + 1, j, i) - ZR(nz, j, i);
+    if (k <= nz) {
       G.zydx[I3(k, j, i)] = hlf * ((ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
       G.zxdy[I3(k, j, i)] = hlf * ((ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
     }
   }
   const double Arz = DX(j, i) * DY(j, i);
-  for (int k = 1; k <= nz + 1; k++) {
-    const double sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
-    const double sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
-    const double den = (k == 1) ? (ZR(k, j, i) - ZW(k, j, i)) : ((k == nz + 1) ? (ZW(k, j, i) - ZR(k - 1, j, i)) : (ZR(k, j, i) - ZR(k - 1, j, i)));
-    CW(k, j, i) = (Arz / den) * (one + sx * sx + sy * sy);
-  }
+  const double sx = (hlf * (ZW(k, j, i + 1) - ZW(k, j, i - 1)) / DX(j, i));
+  const double sy = (hlf * (ZW(k, j + 1, i) - ZW(k, j - 1, i)) / DY(j, i));
+  const double den = (k == 1) ? (ZR(k, j, i) - ZW(k, j, i)) : ((k == nz + 1) ? (ZW(k, j, i) - ZR(k - 1, j, i)) : (ZR(k, j, i) - ZR(k - 1, j, i)));
+  CW(k, j, i) = (Arz / den) * (one + sx * sx + sy * sy);
 }
 
 // mg_define_matrix.f90:352-609: off-diagonal slots (bmask = .false., umask = vmask = 1).
 // Loop ranges of the reference: slots 3,4,5(k>1): i=1..nx, j=1..ny+1 ; slots 6,7,8(k>1): i=1..nx+1, j=1..ny ;
 // cA(5,1): i=1..nx+1, j=0..ny ; cA(8,1): i=1..nx+1, j=1..ny+1 ; cA(2): interior.
 __global__ void k_cA_offdiag(GeoView G) {
-  COLUMN_THREAD(0, G.ny + 1, 1, G.nx + 1)
+  KCOL_THREAD(G.nz, 0, G.ny + 1, 1, G.nx + 1)
   const double one = 1.0, qrt = 0.25, hlf = 0.5;
   const bool in345 = (i <= nx) && (j >= 1);
   const bool in678 = (j >= 1) && (j <= ny);
-  int k = 1;
+  if (k == 1) {
   if (in345) {
     CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
                             (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
@@ -178,7 +189,7 @@ __global__ void k_cA_offdiag(GeoView G) {
                 ((hlf * (ZR(k, j + 1, i - 1) - ZR(k, j - 1, i - 1)) / DY(j, i - 1)) * DX(j, i - 1)) /
                 (CW(k, j, i - 1) + CW(k + 1, j, i - 1)) * UM(j, i) * VM(j, i - 1);
   }
-  for (k = 2; k <= nz - 1; k++) {
+  } else if (k <= nz - 1) {
     if (in345 && j <= ny) {
       CA(2, k, j, i) = CW(k, j, i);
       if (G.bmask)  // :497-509
@@ -204,8 +215,7 @@ __global__ void k_cA_offdiag(GeoView G) {
       CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
                                ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
     }
-  }
-  k = nz;
+  } else {
   if (in345 && j <= ny) CA(2, k, j, i) = CW(k, j, i);
   if (in345) {
     CA(4, k, j, i) =
@@ -225,22 +235,23 @@ __global__ void k_cA_offdiag(GeoView G) {
     CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
                              ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
   }
+  }
 }
 
 // mg_define_matrix.f90:616-657: diagonal, interior columns
 __global__ void k_cA_diag(GeoView G) {
-  COLUMN_THREAD(1, G.ny, 1, G.nx)
+  KCOL_THREAD(G.nz, 1, G.ny, 1, G.nx)
   const double hlf = 0.5;
-  int k = 1;
+  if (k == 1)
   CA(1, k, j, i) = -CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
                    - CA(6, k, j, i) - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(5, k + 1, j + 1, i)
                    - CA(5, k, j, i) - CA(5, k, j - 1, i + 1) - CA(8, k, j, i) - CA(8, k, j + 1, i + 1);
-  for (k = 2; k <= nz - 1; k++)
+  else if (k <= nz - 1)
     CA(1, k, j, i) = -CA(2, k, j, i) - CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i)
                      - CA(7, k, j, i + 1) - CA(6, k, j, i) - CA(6, k - 1, j, i + 1) - CA(8, k, j, i)
                      - CA(8, k + 1, j, i + 1) - CA(3, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i)
                      - CA(5, k + 1, j + 1, i);
-  k = nz;
+  else
   CA(1, k, j, i) = -CA(2, k, j, i) - CW(k + 1, j, i)
                    + hlf * (hlf * (ZR(k, j, i + 2) - ZR(k, j, i)) / DX(j, i + 1)) * DY(j, i + 1)
                    - hlf * (hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1)
@@ -288,6 +299,7 @@ __global__ void k_pivots(LevView L) {
 // ------------------------------------------------------------------------------------------------
 static inline dim3 cgrid(int nj, int ni) { return dim3((nj + 63) / 64, (ni + 3) / 4); }
 static const dim3 CBLK(64, 4);
+static inline dim3 kgrid(int nk, int nj, int ni) { return dim3((unsigned)(((long long)nk * nj * ni + 255) / 256)); }
 
 extern "C" {
 void mgxs_coarsen2d(hipStream_t st, const double *src, double *dst, int nyf, int nyc, int nxc, double fac) {
@@ -303,10 +315,10 @@ void mgxs_zr_zw(hipStream_t st, const GeoView *G, double hlim, double theta_b, d
 }
 void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
   if (phase == 0) {
-    hipLaunchKernelGGL(k_cw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, lev1);
-    hipLaunchKernelGGL(k_cA_offdiag, cgrid(G->ny + 2, G->nx + 1), CBLK, 0, st, *G);
+    hipLaunchKernelGGL(k_cw, kgrid(G->nz + 1, G->ny + 2, G->nx + 2), dim3(256), 0, st, *G, lev1);
+    hipLaunchKernelGGL(k_cA_offdiag, kgrid(G->nz, G->ny + 2, G->nx + 1), dim3(256), 0, st, *G);
   } else {
-    hipLaunchKernelGGL(k_cA_diag, cgrid(G->ny, G->nx), CBLK, 0, st, *G);
+    hipLaunchKernelGGL(k_cA_diag, kgrid(G->nz, G->ny, G->nx), dim3(256), 0, st, *G);
   }
 }
 void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
