@@ -9,6 +9,11 @@ import subprocess
 
 import numpy as np
 
+# The emulated ranks are spread over OpenMP threads.  On a many-core host with a small CPU quota (the GPU boxes: 16 cores'
+# worth of a much larger machine) libgomp's default -- one spinning thread per visible CPU -- starves the one thread that
+# has work: cap the team unless the caller chose otherwise.  Must happen before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmgoracle.so")
 
