@@ -982,6 +982,109 @@ __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, do
 // ------------------------------------------------------------------------------------------------
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
 
+// Register-resident relax of a level with <= 1024 columns (the coarsest levels: 16x16x2, and 16x16x4 / 32x32x2 class
+// grids): ONE workgroup, one thread per column for the whole call.  Everything that does not change between colour
+// passes -- b, the 7 own off-diagonal slots and pivots, the 6 neighbour slots the symmetric storage makes a column
+// read, the k=1 diagonal slots, gam -- is loaded into registers once; only p lives in LDS (with its mirrored halo) and
+// is exchanged there.  A colour pass is then ~4 NZ LDS reads, ~30 NZ flops and one barrier (0.1-0.2 us instead of
+// 0.8 us with every operand re-read from LDS, and ~5 us as a separate launch): relax(nlevs, ns_coarsest=40) is 160
+// dependent passes.  Same expressions in the same order as relax_col_nz: bit-identical.
+template <int NZ, bool REAL, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_relax_reg(LevView G, int nsweeps, int method, Sides ph) {
+  extern __shared__ double ldsr[];
+  double *lds = ldsr;
+  const int nx = G.nx, ny = G.ny, W = ny + 2, PL = (nx + 2) * W;  // P[k][i][j]
+  double *__restrict__ P = lds, *__restrict__ P1 = lds + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
+  const int tid = threadIdx.x, nth = blockDim.x;
+#define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
+  for (int t = tid; t < NZ * PL; t += nth) {
+    const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W;
+    P[t] = G.p[GI(k0, j, i)];
+  }
+  const int j = 1 + tid % ny, i = 1 + tid / ny;
+  const bool mine = tid < nx * ny;
+  double ob[NZ], a2[NZ], a3[NZ], a4[NZ], a5[NZ], a6[NZ], a7[NZ], a8[NZ], bet[NZ], g[NZ];
+  double r3[NZ], r4[NZ], r5[NZ], r6[NZ], r7[NZ], r8[NZ], e2 = 0, e4 = 0;
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      const long long c = GI(k, j, i), cj = GI(k, j + 1, i), ci = GI(k, j, i + 1);
+      ob[k] = G.b[c]; a2[k] = G.cA[1][c]; a3[k] = G.cA[2][c]; a4[k] = G.cA[3][c]; a5[k] = G.cA[4][c];
+      a6[k] = G.cA[5][c]; a7[k] = G.cA[6][c]; a8[k] = G.cA[7][c]; bet[k] = G.bet[c];
+      r3[k] = G.cA[2][cj]; r4[k] = G.cA[3][cj]; r5[k] = G.cA[4][cj];
+      r6[k] = G.cA[5][ci]; r7[k] = G.cA[6][ci]; r8[k] = G.cA[7][ci];
+    }
+    if (REAL) { e2 = G.cA[4][GI(0, j - 1, i + 1)]; e4 = G.cA[7][GI(0, j + 1, i + 1)]; }
+    g[0] = 0.0;
+#pragma unroll
+    for (int k = 1; k < NZ; k++) g[k] = a2[k] * bet[k - 1];  // gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325)
+  }
+  __syncthreads();
+  const bool mS = ph.S && j == 1, mN = ph.N && j == ny, mW = ph.W && i == 1, mE = ph.E && i == nx;
+  const int ncolour = method == 2 ? 4 : 2;
+  for (int it = 0; it < nsweeps; it++) {
+    for (int cidx = 0; cidx < ncolour; cidx++) {
+      if (method == 1 && REAL) {
+        for (int t = tid; t < PL; t += nth) P1[t] = P[t];
+        __syncthreads();
+      }
+      bool active;
+      if (method == 2) active = ((i & 1) == ((cidx >> 1) ? 0 : 1)) && ((j & 1) == ((cidx & 1) ? 0 : 1));  // mg_relax.f90:214-217
+      else active = (j & 1) == ((((i + cidx + 1) & 1) == 0) ? 1 : 0);                                        // :174
+      if (mine && active) {
+        double x[NZ];
+        const double *__restrict__ Q1 = (method == 1 && REAL) ? P1 : P;
+        double d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+        if (REAL) { d1 = Q1[(i - 1) * W + j + 1]; d2 = Q1[(i + 1) * W + j - 1]; d3 = Q1[(i - 1) * W + j - 1]; d4 = Q1[(i + 1) * W + j + 1]; }
+        double pjm[NZ], pjp[NZ], pim[NZ], pip[NZ];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          const int o = k * PL + i * W + j;
+          pjm[k] = P[o - 1]; pjp[k] = P[o + 1]; pim[k] = P[o - W]; pip[k] = P[o + W];
+        }
+        double xv = 0.0;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          double rhs;
+          if (k == 0) {
+            rhs = ob[k] - a3[k] * pjm[k + 1] - a4[k] * pjm[k] - r4[k] * pjp[k] - r5[k + 1] * pjp[k + 1]
+                        - a6[k] * pim[k + 1] - a7[k] * pim[k] - r7[k] * pip[k] - r8[k + 1] * pip[k + 1];
+            if (REAL) rhs = rhs - a5[0] * d1 - e2 * d2 - a8[0] * d3 - e4 * d4;
+            xv = rhs * bet[k];
+          } else if (k < NZ - 1) {
+            rhs = ob[k] - a3[k] * pjm[k + 1] - r3[k - 1] * pjp[k - 1] - a4[k] * pjm[k] - r4[k] * pjp[k] - a5[k] * pjm[k - 1] - r5[k + 1] * pjp[k + 1]
+                        - a6[k] * pim[k + 1] - r6[k - 1] * pip[k - 1] - a7[k] * pim[k] - r7[k] * pip[k] - a8[k] * pim[k - 1] - r8[k + 1] * pip[k + 1];
+            xv = (rhs - a2[k] * xv) * bet[k];
+          } else {
+            rhs = ob[k] - r3[k - 1] * pjp[k - 1] - a4[k] * pjm[k] - r4[k] * pjp[k] - a5[k] * pjm[k - 1]
+                        - r6[k - 1] * pip[k - 1] - a7[k] * pim[k] - r7[k] * pip[k] - a8[k] * pim[k - 1];
+            xv = (rhs - a2[k] * xv) * bet[k];
+          }
+          x[k] = xv;
+        }
+#pragma unroll
+        for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - g[k + 1] * x[k + 1];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          const int o = k * PL;
+          const double v = x[k];
+          P[o + i * W + j] = v;
+          if (mS) P[o + i * W] = v;
+          if (mN) P[o + i * W + ny + 1] = v;
+          if (mW) { P[o + j] = v; if (mS) P[o] = v; if (mN) P[o + ny + 1] = v; }
+          if (mE) { P[o + (nx + 1) * W + j] = v; if (mS) P[o + (nx + 1) * W] = v; if (mN) P[o + (nx + 1) * W + ny + 1] = v; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = tid; t < NZ * PL; t += nth) {
+    const int k0 = t / PL, r = t - k0 * PL, ii = r / W, jj = r - ii * W;
+    G.p[GI(k0, jj, ii)] = P[t];
+  }
+#undef GI
+}
+
 // Coarsest-level solve entirely out of LDS: when p, b, slots 2..8 and the pivots of a level fit in 64 KB (16x16x2:
 // 57 KB), ONE workgroup copies them in (compact JS layout), runs all nsweeps x colours with the same column routine
 // (its pointers now address LDS), and writes p back.  relax(nlevs, ns_coarsest=40) = 160 dependent colour passes:
@@ -1090,6 +1193,20 @@ int mgxk_relax_gs_sweep(hipStream_t st, const LevView *L, int real) {
 
 // one-launch relax of a small level; returns 0 if the level does not qualify
 int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph) {
+  {  // one thread per column, coefficients in registers, p in LDS
+    static const bool noreg = getenv("MGX_NO_REG") != nullptr;
+    const int ncols = L->nx * L->ny;
+    const bool closed = ph.S && ph.E && ph.N && ph.W;
+    if (!noreg && closed && method != 0 && ((L->nz == 2 && ncols <= 1024) || (L->nz == 4 && ncols <= 256))) {
+      const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
+      const int nth = (ncols + 63) / 64 * 64;
+      if (L->nz == 2) { if (real) hipLaunchKernelGGL((k_relax_reg<2, true, 1024>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph);
+                        else hipLaunchKernelGGL((k_relax_reg<2, false, 1024>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph); }
+      else { if (real) hipLaunchKernelGGL((k_relax_reg<4, true, 256>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph);
+             else hipLaunchKernelGGL((k_relax_reg<4, false, 256>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph); }
+      return 1;
+    }
+  }
   {  // everything in LDS? (11 arrays of the compact level + the k=1 snapshot)
     static const bool notiny = getenv("MGX_NO_TINY") != nullptr;
     const size_t n3 = (size_t)(L->nx + 2) * (L->ny + 2) * L->nz, bytes = (11 * n3 + (size_t)(L->nx + 2) * (L->ny + 2)) * sizeof(double);
