@@ -1221,6 +1221,9 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
     }
   }
   const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
+  // (Measured and dropped: one cooperative launch per relax call with a grid-wide barrier between colour passes on the
+  // 1024-16384-column levels -- cg grid.sync and a hand-written atomic barrier both cost more than the kernel boundary
+  // they replace: V-cycle 2.81 -> 3.03 ms.)
   // one CU streams ~25-50 GB/s: worth it only while the level is launch-bound, not bandwidth-bound (measured:
   // 16x16x2 and 32x32x4 win, 64x64x8 loses 2x against separate launches over 256 CUs).  A 2-level-deep coarsest grid
   // is still launch-bound at 1024 columns per colour (the gathered 64x32x2 grid of an 8-GPU run): 1024 threads.
