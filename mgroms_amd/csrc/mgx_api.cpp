@@ -37,7 +37,7 @@ void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const doubl
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, unsigned long long *const *, const int *, unsigned long long,
-                   unsigned int *, int *, int);
+                   unsigned int *, int *, int, const int *);
 void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
 void mgxk_convert8(hipStream_t, const LevView *, const double *);
@@ -228,6 +228,15 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
     const int c = L.nz * ((d == 0 || d == 2) ? L.nx : ((d == 1 || d == 3) ? L.ny : 1));
     peer[n] = nb[d]; cnt[n] = c; sb[n] = S.xbuf[d]; rb[n] = S.xbuf[8 + d]; n++;
   }
+  int m[4] = {0, 0, 0, 0};  // mixed corners SW,SE,NE,NW: 1 = copy across the physical W/E side, 2 = across S/N (:720-743)
+  bool any = false;
+  if (n) {
+    const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
+    for (int c = 0; c < 4; c++) {
+      if (nb[4 + c] < 0) { if (nb[side1[c]] >= 0) m[c] = 1; else if (nb[side2[c]] >= 0) m[c] = 2; }
+      any |= m[c] != 0;
+    }
+  }
   if (n && S.p2p_on) {  // push into the neighbours' receive buffers over xGMI, then wait on the local flags: no host step
     static const int opp[8] = {2, 3, 0, 1, 6, 7, 4, 5};
     const unsigned long long seq = ++L.p2p_seq;
@@ -242,23 +251,13 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
       lbuf[d] = S.p2p_slab + L.p2p_off[d][par];
       lflag[d] = S.p2p_flags + (li * 8 + d) * 2 + par;
     }
-    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, rflag, present, seq, S.p2p_counter, S.p2p_err, 0);
-    mgxk_halo_p2p(S.stream, &L.v, a, lbuf, lflag, present, seq, S.p2p_counter, S.p2p_err, 1);
+    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, rflag, present, seq, S.p2p_counter, S.p2p_err, 0, m);
+    mgxk_halo_p2p(S.stream, &L.v, a, lbuf, lflag, present, seq, S.p2p_counter, S.p2p_err, 1, m);  // mixed corners included
     S.n_launch += 2; S.n_p2p++;
   } else if (n) {
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf, present, 0); S.n_launch++;       // all edges + corners, one launch
     CHK(exchange(n, peer, sb, rb, cnt));
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf + 8, present, 1); S.n_launch++;
-  }
-  if (n) {
-    int m[4];
-    const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
-    bool any = false;
-    for (int c = 0; c < 4; c++) {
-      m[c] = 0;
-      if (nb[4 + c] < 0) { if (nb[side1[c]] >= 0) m[c] = 1; else if (nb[side2[c]] >= 0) m[c] = 2; }
-      any |= m[c] != 0;
-    }
     if (any) { mgxk_halo_mixed_corners(S.stream, &L.v, a, m[0], m[1], m[2], m[3]); S.n_launch++; }
   }
   return 0;

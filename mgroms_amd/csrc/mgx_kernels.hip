@@ -982,6 +982,7 @@ struct HaloP2P {
   unsigned long long seq;
   unsigned int *counter;        // blocks-done counter of the push launch (device memory, left at 0)
   int *err;                     // host-mapped error word: 1 = a wait timed out
+  int mSW, mSE, mNE, mNW;       // unpack: mixed corners (one side physical, the other a neighbour), see k_halo_mixed_corners
 };
 __global__ void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
   const int dir = blockIdx.z;
@@ -1018,8 +1019,18 @@ __global__ void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs h
   if (!ok) { if (threadIdx.x == 0) *pp.err = 1; return; }
   __threadfence_system();
   long long e, t;
-  if (!halo_elem(L, dir, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, 1, e, t)) return;
-  a[e] = __builtin_nontemporal_load(hb.b[dir] + t);
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (!halo_elem(L, dir, q, k, 1, e, t)) return;
+  const double v = __builtin_nontemporal_load(hb.b[dir] + t);
+  a[e] = v;
+  // mixed corners (mg_mpi_exchange.f90:720-743): the corner next to a physical side mirrors the edge halo cell that was
+  // just received -- written here by the thread that unpacked that cell instead of a separate launch
+  const int nx = L.nx, ny = L.ny;
+  const long long ro = (long long)k * L.RS, W0 = ro, E0 = (long long)(nx + 1) * L.plane + ro;
+  if (dir == 0) { if (q == 0 && pp.mSW == 1) a[W0 + jpos(L, 0)] = v; if (q == nx - 1 && pp.mSE == 1) a[E0 + jpos(L, 0)] = v; }
+  else if (dir == 2) { if (q == 0 && pp.mNW == 1) a[W0 + jpos(L, ny + 1)] = v; if (q == nx - 1 && pp.mNE == 1) a[E0 + jpos(L, ny + 1)] = v; }
+  else if (dir == 3) { if (q == 0 && pp.mSW == 2) a[W0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNW == 2) a[W0 + jpos(L, ny + 1)] = v; }
+  else if (dir == 1) { if (q == 0 && pp.mSE == 2) a[E0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNE == 2) a[E0 + jpos(L, ny + 1)] = v; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1485,10 +1496,11 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
   hipLaunchKernelGGL(k_halo_pack_all, dim3((n + 63) / 64, L->nz, 8), dim3(64), 0, st, *L, a, hb, unpack);
 }
 void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *bufs, unsigned long long *const *flags, const int *present,
-                   unsigned long long seq, unsigned int *counter, int *err, int unpack) {
+                   unsigned long long seq, unsigned int *counter, int *err, int unpack, const int *mixed) {
   HaloBufs hb; HaloP2P pp;
   for (int d = 0; d < 8; d++) { hb.b[d] = bufs[d]; hb.present[d] = present[d]; pp.flag[d] = flags[d]; }
   pp.seq = seq; pp.counter = counter; pp.err = err;
+  pp.mSW = mixed[0]; pp.mSE = mixed[1]; pp.mNE = mixed[2]; pp.mNW = mixed[3];
   const int n = L->nx > L->ny ? L->nx : L->ny;
   const dim3 grid((n + 63) / 64, L->nz, 8);
   if (unpack) hipLaunchKernelGGL(k_halo_wait_unpack, grid, dim3(64), 0, st, *L, a, hb, pp);
