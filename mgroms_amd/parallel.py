@@ -159,22 +159,29 @@ class Comm:
         L = lib()
         nb = L.mgx_p2p_handle_bytes()
         blob = C.create_string_buffer(nb)
-        check(L.mgx_p2p_prepare(blob))
-        mine = torch.frombuffer(bytearray(blob.raw), dtype=torch.uint8).clone()
-        if not self.staged:
-            mine = mine.cuda()
+        dev = "cpu" if self.staged else "cuda"
+
+        def all_ok(flag):  # every step is all-or-nothing: a rank that fails must not leave the others in a collective
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return int(t.item()) == 1
+
+        def give_up(msg):
+            self.p2p_error = msg
+            L.mgx_set_option(b"p2p", 0)
+            self.p2p_active = False
+            return False
+
+        rc = L.mgx_p2p_prepare(blob)
+        if not all_ok(rc == 0):
+            return give_up(L.mgx_last_error().decode() if rc else "a peer could not export its halo buffers (hipIpcGetMemHandle)")
+        mine = torch.frombuffer(bytearray(blob.raw), dtype=torch.uint8).clone().to(dev)
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         allh = b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
         rc = L.mgx_p2p_connect(allh, self.world)
-        # all or nothing: one rank that cannot open a neighbour's memory sends everybody back to the callback
-        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cpu" if self.staged else "cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok.item()) == 0:
-            self.p2p_error = L.mgx_last_error().decode() if rc else "a peer could not open the shared halo buffers"
-            L.mgx_set_option(b"p2p", 0)
-            self.p2p_active = False
-            return False
+        if not all_ok(rc == 0):
+            return give_up(L.mgx_last_error().decode() if rc else "a peer could not open the shared halo buffers (hipIpcOpenMemHandle)")
         self.p2p_active = True
         return self._p2p_selftest()
 
