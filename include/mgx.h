@@ -120,7 +120,8 @@ int mgx_set_verbose(int level);
 
 /* Options (0/1): "warm_start" keep p between solves instead of the cold start of mg_solvers.f90:35;
  * "tictoc" per-(level,name) timers like mg_tictoc.f90 (HIP events); "exact_halos" exchange the never-read r/b halos
- * eagerly as the reference does; "verbose". */
+ * eagerly as the reference does; "verbose"; "p2p" (see below); "rb_chain" (default 1) red-black with cmatrix='real' on a
+ * single-rank level: the colour passes write the next sweep's k=1 snapshot themselves, 0 = one snapshot launch per pass. */
 int mgx_set_option(const char *name, int value);
 /* print_tictoc (mg_tictoc.f90:114-153): timer table (seconds, calls per level) to `path` (NULL = "fort.10") */
 int mgx_print_tictoc(const char *path);

@@ -29,6 +29,7 @@ int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
+int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
@@ -85,6 +86,7 @@ struct Level {
   unsigned long long p2p_seq = 0;  // exchanges done on this level through the peer-to-peer transport
   size_t p2p_goff[2];           // gathered levels: ngroup blocks of the peer-to-peer gather, by parity
   unsigned long long p2p_gseq = 0;
+  double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
 };
 
@@ -115,6 +117,7 @@ struct State {
   int verbose = 1;
   int warm_start = 0;   // keep p between solves instead of the reference's cold start (mg_solvers.f90:35)
   int tictoc = 0;       // per-(level,name) GPU timers in the shape of mg_tictoc.f90
+  int rb_chain = 1;     // red-black: chained k=1 snapshots on closed levels (0 = one snapshot launch per colour pass, for A/B tests)
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
@@ -407,13 +410,25 @@ int relax(int lev, int nsweeps) {
   }
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph)) { S.n_launch++; return 0; }
+  const bool closed = ph.S && ph.E && ph.N && ph.W;
+  double *const p1a = L.v.p1;
   for (int it = 1; it <= nsweeps; it++) {
     if (S.method == M_RB) {
+      // cmatrix='real': the k=1 diagonal neighbours have the column's own colour and must be read as they were before the
+      // pass (snapshot).  On a closed level the register kernels write the next sweep's snapshot themselves (two buffers
+      // swapped per sweep: a pass reads only entries of its own colour, which the other colour's pass never touches), so
+      // one snapshot launch per relax call suffices; with neighbours the halo part changes after every exchange.
+      const bool chain = S.rb_chain && S.real && closed && mgxk_has_reg_kernel(&L.v);
+      if (chain) {
+        if (it == 1) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
+        L.v.p1w = (L.v.p1 == p1a) ? L.p1b : p1a;
+      }
       for (int rb = 1; rb <= 2; rb++) {
-        if (S.real) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
+        if (S.real && !chain) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
         const int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
         CHK(fill_halo_js(L, L.v.p, fused));
       }
+      if (chain) { L.v.p1 = L.v.p1w; L.v.p1w = nullptr; if (it == nsweeps) L.v.p1 = p1a; }
     } else {
       for (int fc1 = 1; fc1 <= 2; fc1++)
         for (int fc2 = 1; fc2 <= 2; fc2++) {
@@ -867,7 +882,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     CHK(dmalloc(&L.v.p, L.n3js)); CHK(dmalloc(&L.v.b, L.n3js)); CHK(dmalloc(&L.v.r, L.n3js));
     for (int s = 0; s < 8; s++) CHK(dmalloc(&L.v.cA[s], L.n3js));
     CHK(dmalloc(&L.v.bet, L.n3js)); CHK(dmalloc(&L.v.gam, L.n3js));
-    CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS));
+    CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.p1b, (size_t)(L.nx + 2) * L.v.RS)); L.v.p1w = nullptr;
     CHK(dmalloc(&L.zy_store, L.n3js)); CHK(dmalloc(&L.zx_store, L.n3js));
     L.v.zy = L.v.zx = nullptr;
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
@@ -1045,6 +1060,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "tictoc")) S.tictoc = value;
   else if (streq(name, "exact_halos")) S.exact_halos = value;
   else if (streq(name, "verbose")) S.verbose = value;
+  else if (streq(name, "rb_chain")) S.rb_chain = value;
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;

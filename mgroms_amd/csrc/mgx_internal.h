@@ -17,6 +17,7 @@ struct LevView {
   double *bet;      // reciprocal pivots of the column tridiagonal (tridiag's `bet`, mg_relax.f90:322-327)
   double *gam;      // tridiag's `gam(k)` (mg_relax.f90:325)
   double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
+  double *p1w;      // when set: the colour pass also writes its new k=1 values here (= the snapshot of the NEXT sweep)
   double *zy, *zx;  // slopes ZY, ZX (JS layout) for the matrix-free cross terms; nullptr = use the stored slots
 };
 

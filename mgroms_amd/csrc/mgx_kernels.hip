@@ -239,6 +239,21 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
   }
+  if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry of this column (and its physical mirrors): no snapshot launch per pass
+    // A mirrored halo cell is read (as a k=1 diagonal) only by columns of the OTHER colour, i.e. by the next pass of this
+    // same sweep, which must see it updated: mirrors go to the buffer being read as well (no column of this pass reads them,
+    // except a corner column its own corner, after which it is the one to overwrite it).
+    double *w1 = L.p1w, *r1 = L.p1;
+    const long long so = (long long)i * RS, sW = 0, sE = (long long)(L.nx + 1) * RS;
+    const double v1 = x[0];
+    w1[so + c] = v1;
+#define SNAP_MIRROR(idx) { w1[idx] = v1; r1[idx] = v1; }
+    if (mS) SNAP_MIRROR(so + cS)
+    if (mN) SNAP_MIRROR(so + cN)
+    if (mW) { SNAP_MIRROR(sW + c) if (mS) SNAP_MIRROR(sW + cS) if (mN) SNAP_MIRROR(sW + cN) }
+    if (mE) { SNAP_MIRROR(sE + c) if (mS) SNAP_MIRROR(sE + cS) if (mN) SNAP_MIRROR(sE + cN) }
+#undef SNAP_MIRROR
+  }
 #undef NB_LOAD
 #undef OW_LOAD
 #undef NB_USE
@@ -358,6 +373,21 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     if (mN) p[o + ro + cN] = v;
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
+  }
+  if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry of this column (and its physical mirrors): no snapshot launch per pass
+    // A mirrored halo cell is read (as a k=1 diagonal) only by columns of the OTHER colour, i.e. by the next pass of this
+    // same sweep, which must see it updated: mirrors go to the buffer being read as well (no column of this pass reads them,
+    // except a corner column its own corner, after which it is the one to overwrite it).
+    double *w1 = L.p1w, *r1 = L.p1;
+    const long long so = (long long)i * RS, sW = 0, sE = (long long)(L.nx + 1) * RS;
+    const double v1 = x[0];
+    w1[so + c] = v1;
+#define SNAP_MIRROR(idx) { w1[idx] = v1; r1[idx] = v1; }
+    if (mS) SNAP_MIRROR(so + cS)
+    if (mN) SNAP_MIRROR(so + cN)
+    if (mW) { SNAP_MIRROR(sW + c) if (mS) SNAP_MIRROR(sW + cS) if (mN) SNAP_MIRROR(sW + cN) }
+    if (mE) { SNAP_MIRROR(sE + c) if (mS) SNAP_MIRROR(sE + cS) if (mN) SNAP_MIRROR(sE + cN) }
+#undef SNAP_MIRROR
   }
 #undef NB_LOAD
 #undef OW_LOAD
@@ -496,6 +526,21 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     LOW_LOAD(q + DB)
     STORE_ROW(LOW - q, xk)
     xn = xk;
+  }
+  if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry of this column (and its physical mirrors): no snapshot launch per pass
+    // A mirrored halo cell is read (as a k=1 diagonal) only by columns of the OTHER colour, i.e. by the next pass of this
+    // same sweep, which must see it updated: mirrors go to the buffer being read as well (no column of this pass reads them,
+    // except a corner column its own corner, after which it is the one to overwrite it).
+    double *w1 = L.p1w, *r1 = L.p1;
+    const long long so = (long long)i * RS, sW = 0, sE = (long long)(L.nx + 1) * RS;
+    const double v1 = xn;
+    w1[so + c] = v1;
+#define SNAP_MIRROR(idx) { w1[idx] = v1; r1[idx] = v1; }
+    if (mS) SNAP_MIRROR(so + cS)
+    if (mN) SNAP_MIRROR(so + cN)
+    if (mW) { SNAP_MIRROR(sW + c) if (mS) SNAP_MIRROR(sW + cS) if (mN) SNAP_MIRROR(sW + cN) }
+    if (mE) { SNAP_MIRROR(sE + c) if (mS) SNAP_MIRROR(sE + cS) if (mN) SNAP_MIRROR(sE + cN) }
+#undef SNAP_MIRROR
   }
 #undef LOW_LOAD
 #undef STORE_ROW
@@ -1453,6 +1498,10 @@ int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int n
   else if (real) hipLaunchKernelGGL((k_relax_colour<true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
   else hipLaunchKernelGGL((k_relax_colour<false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
   return 0;
+}
+// does mgxk_relax_colour run a register-resident kernel (which writes mirrors and chained snapshots) on this level?
+int mgxk_has_reg_kernel(const LevView *L) {
+  switch (L->nz) { case 2: case 4: case 8: case 16: case 32: case 64: return 1; case 128: return L->zy != nullptr && getenv("MGX_NO_TALL") == nullptr; default: return 0; }
 }
 void mgxk_snapshot_k1(hipStream_t st, const LevView *L) {
   hipLaunchKernelGGL(k_snapshot_k1, dim3((L->RS + 255) / 256, L->nx + 2), dim3(256), 0, st, *L);

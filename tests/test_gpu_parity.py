@@ -112,6 +112,27 @@ def test_relax_rb_simple_bitwise(mg):
         assert np.array_equal(g.get("p"), o.field("p", lev)), lev
 
 
+def test_relax_rb_chained_snapshot_is_exact(mg):
+    # cmatrix='real' red-black reads same-colour k=1 diagonals from a snapshot taken before the pass.  On a closed level the
+    # colour passes chain that snapshot themselves (one launch per relax call): must equal a snapshot launch per pass, bit for bit
+    nx, ny, nz = 64, 32, 16
+    _setup(mg, nx, ny, nz, relax_method="RB")
+    r = np.random.default_rng(21)
+    out = []
+    for chain in (1, 0):
+        mg.nhydro.set_option("rb_chain", chain)
+        for lev in (1, 2):
+            g = mg.grid(lev)
+            rr = np.random.default_rng(21 + lev)
+            g.set("p", rr.standard_normal(g._shape("p"))); g.set("b", rr.standard_normal(g._shape("b")))
+            mg.fill_halo(lev, "p")
+            mg.relax(lev, 3)
+            out.append(g.get("p"))
+    mg.nhydro.set_option("rb_chain", 1)
+    assert np.array_equal(out[0], out[2]) and np.array_equal(out[1], out[3])
+    assert np.abs(out[0]).max() > 0
+
+
 def test_relax_rb_real_close(mg):
     # with cmatrix='real' a red column reads its four same-colour diagonal neighbours at k=1: the sequential sweep
     # sees some of them updated, the parallel sweep sees all of them old -> O(diagonal coupling) difference only
