@@ -366,8 +366,8 @@ void tic(int lev, const char *name) {
   if (!S.tictoc) return;
   TicRec r; r.lev = lev; r.sub = tt_sub(name);
   if (r.sub >= 32 || lev > 32) return;
-  hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-  hipEventRecord(r.e0, S.stream);
+  (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, S.stream);
   tt_open.push_back(r);
 }
 void toc(int lev, const char *name) {
@@ -375,7 +375,7 @@ void toc(int lev, const char *name) {
   const int sub = tt_sub(name);
   for (int q = (int)tt_open.size() - 1; q >= 0; q--)
     if (tt_open[q].lev == lev && tt_open[q].sub == sub) {
-      hipEventRecord(tt_open[q].e1, S.stream);
+      (void)hipEventRecord(tt_open[q].e1, S.stream);
       tt_done.push_back(tt_open[q]);
       tt_open.erase(tt_open.begin() + q);
       if (lev > tt_nblev) tt_nblev = lev;
@@ -384,11 +384,11 @@ void toc(int lev, const char *name) {
 }
 void tt_collect() {
   if (tt_done.empty()) return;
-  hipStreamSynchronize(S.stream);
+  (void)hipStreamSynchronize(S.stream);
   for (auto &r : tt_done) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tt_time[r.lev - 1][r.sub] += ms * 1e-3; tt_calls[r.lev - 1][r.sub]++; }
-    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   tt_done.clear();
 }
@@ -827,10 +827,10 @@ int mgx_read_namelist(const char *path, mgx_params *p) {
 }
 
 void mgx_clean(void) {
-  if (S.stream || S.inited) hipStreamSynchronize(S.stream);
+  if (S.stream || S.inited) (void)hipStreamSynchronize(S.stream);
   p2p_release();
-  for (void *q : S.allocs) hipFree(q);
-  if (S.h_scalar) hipHostFree(S.h_scalar);
+  for (void *q : S.allocs) (void)hipFree(q);
+  if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   tt_collect();
   hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx;
@@ -1168,7 +1168,7 @@ static int time_op(int lev, int reps, float *ms, int which) {
   HIPCHK(hipEventRecord(e1, S.stream));
   HIPCHK(hipEventSynchronize(e1));
   float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms = t / reps;
   return 0;
 }
