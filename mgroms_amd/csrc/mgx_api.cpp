@@ -471,13 +471,14 @@ int fine2coarse(int lev) {
       if (me < 0) return fail("gather: rank %d is not in its own group on level %d", S.rank, lev + 1);
       double *dst[4]; unsigned long long *rflag[4];
       for (int q = 0; q < C.ngroup; q++) {
-        dst[q] = S.peer_slab[C.group[q]] + C.p2p_goff[par] + (size_t)me * Ng;
+        // my own copy stays in ordinary device memory (C.blk): stores to the fine-grained slab are uncached and slow
+        dst[q] = q == me ? C.blk : S.peer_slab[C.group[q]] + C.p2p_goff[par] + (size_t)me * Ng;
         rflag[q] = S.peer_flags[C.group[q]] + 1024 + (li * 4 + me) * 2 + par;
       }
       mgxk_gather_push(S.stream, &C.vs, C.vs.b, dst, rflag, C.ngroup, me, seq, S.p2p_counter, S.p2p_err); S.n_launch++;
       for (int q = 0; q < C.ngroup; q++) {
         unsigned long long *lflag = q == me ? nullptr : S.p2p_flags + 1024 + (li * 4 + q) * 2 + par;
-        mgxk_gather_place_wait(S.stream, &C.v, C.v.b, S.p2p_slab + C.p2p_goff[par] + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx, lflag, seq, S.p2p_err);
+        mgxk_gather_place_wait(S.stream, &C.v, C.v.b, q == me ? C.blk : S.p2p_slab + C.p2p_goff[par] + (size_t)q * Ng, C.vs.nx, C.vs.ny, q % C.ngx, q / C.ngx, lflag, seq, S.p2p_err);
         S.n_launch++;
       }
       S.n_p2p++;

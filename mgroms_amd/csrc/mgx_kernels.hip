@@ -1028,18 +1028,27 @@ struct HaloP2P {
   unsigned int *counter;        // blocks-done counter of the push launch (device memory, left at 0)
   int *err;                     // host-mapped error word: 1 = a wait timed out
   int mSW, mSE, mNE, mNW;       // unpack: mixed corners (one side physical, the other a neighbour), see k_halo_mixed_corners
+  int blk0[9];                  // compact 1-D grid: blocks blk0[d] .. blk0[d+1]-1 serve direction d (empty when absent)
 };
-__global__ void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
-  const int dir = blockIdx.z;
-  if (hb.present[dir]) {
-    long long e, t;
-    if (halo_elem(L, dir, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, 0, e, t)) hb.b[dir][t] = a[e];
-  }
-  __threadfence_system();  // this thread's remote writes are performed before the block reports in
+// item w of direction d is buffer element w = k*n_d + q: consecutive lanes = consecutive buffer elements
+__device__ __forceinline__ bool halo_item(const LevView &L, const HaloP2P &pp, int unpack, int &dir, int &q, int &k, long long &e, long long &t) {
+  const int b = blockIdx.x;
+  dir = 0;
+#pragma unroll
+  for (int d = 1; d < 8; d++) if (b >= pp.blk0[d]) dir = d;
+  const int n = (dir == 0 || dir == 2) ? L.nx : ((dir == 1 || dir == 3) ? L.ny : 1);
+  const int w = (b - pp.blk0[dir]) * blockDim.x + threadIdx.x;
+  if (w >= n * L.nz) return false;
+  k = w / n; q = w - k * n;
+  return halo_elem(L, dir, q, k, unpack, e, t);
+}
+__global__ __launch_bounds__(256) void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
+  int dir, q, k; long long e, t;
+  if (halo_item(L, pp, 0, dir, q, k, e, t)) hb.b[dir][t] = a[e];
+  __threadfence_system();  // this wave's remote writes are performed before the block reports in
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-    if (__hip_atomic_fetch_add(pp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+    if (__hip_atomic_fetch_add(pp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(pp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       for (int d = 0; d < 8; d++)
@@ -1047,9 +1056,9 @@ __global__ void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb
     }
   }
 }
-__global__ void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
-  const int dir = blockIdx.z;
-  if (!hb.present[dir]) return;
+__global__ __launch_bounds__(256) void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
+  int dir, q, k; long long e, t;
+  const bool mine = halo_item(L, pp, 1, dir, q, k, e, t);  // dir is block-uniform
   __shared__ int ok;
   if (threadIdx.x == 0) {
     ok = 0;
@@ -1063,9 +1072,7 @@ __global__ void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs h
   __syncthreads();
   if (!ok) { if (threadIdx.x == 0) *pp.err = 1; return; }
   __threadfence_system();
-  long long e, t;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-  if (!halo_elem(L, dir, q, k, 1, e, t)) return;
+  if (!mine) return;
   const double v = __builtin_nontemporal_load(hb.b[dir] + t);
   a[e] = v;
   // mixed corners (mg_mpi_exchange.f90:720-743): the corner next to a physical side mirrors the edge halo cell that was
@@ -1139,12 +1146,13 @@ __global__ void k_block_to_ref(LevView Cs, const double *__restrict__ js, double
 // flag at the other members.  k_gather_place_wait then waits for member q's flag before placing its block.
 struct GatherP2P { double *dst[4]; unsigned long long *flag[4]; int ng, me; unsigned long long seq; unsigned int *counter; int *err; };
 __global__ void k_gather_push(LevView Cs, const double *__restrict__ js, GatherP2P gp) {
+  // block layout in the gather buffers: (i, k, j) with j fastest (halo included) -- lanes run along j on both sides
   const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) {
-    const int k = (int)(t % Cs.nz);
-    const long long ji = t / Cs.nz;
-    const int j = (int)(ji % (Cs.ny + 2)), i = (int)(ji / (Cs.ny + 2));
+    const int j = (int)(t % (Cs.ny + 2));
+    const long long ik = t / (Cs.ny + 2);
+    const int k = (int)(ik % Cs.nz), i = (int)(ik / Cs.nz);
     const double v = js[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)];
     for (int q = 0; q < gp.ng; q++) gp.dst[q][t] = v;
   }
@@ -1179,10 +1187,10 @@ __global__ void k_gather_place_wait(LevView C, double *__restrict__ dstjs, const
   const long long n = (long long)C.nz * nyc * nxc;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const int k = (int)(t % C.nz);
-  const long long ji = t / C.nz;
-  const int j = 1 + (int)(ji % nyc), i = 1 + (int)(ji / nyc);
-  const double v = __builtin_nontemporal_load(blk + ((long long)i * (nyc + 2) + j) * C.nz + k);
+  const int j = 1 + (int)(t % nyc);
+  const long long ik = t / nyc;
+  const int k = (int)(ik % C.nz), i = 1 + (int)(ik / C.nz);
+  const double v = __builtin_nontemporal_load(blk + ((long long)i * C.nz + k) * (nyc + 2) + j);
   dstjs[(long long)(i + l * nxc) * C.plane + (long long)k * C.RS + jpos(C, j + m * nyc)] = v;
 }
 // split (mg_gather.f90:177-220): own quadrant of the gathered p, halo included, into the small JS block
@@ -1547,13 +1555,21 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
 void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *bufs, unsigned long long *const *flags, const int *present,
                    unsigned long long seq, unsigned int *counter, int *err, int unpack, const int *mixed) {
   HaloBufs hb; HaloP2P pp;
-  for (int d = 0; d < 8; d++) { hb.b[d] = bufs[d]; hb.present[d] = present[d]; pp.flag[d] = flags[d]; }
+  int nb = 0;
+  for (int d = 0; d < 8; d++) {
+    hb.b[d] = bufs[d]; hb.present[d] = present[d]; pp.flag[d] = flags[d];
+    pp.blk0[d] = nb;
+    if (present[d]) nb += (L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1)) + 255) / 256;
+  }
+  pp.blk0[8] = nb;
+  // absent directions get an empty range; halo_item picks the LAST d with blk0[d] <= b, so a block lands on the present
+  // direction whose range contains it only if later absent ones do not share its start: push them past the end
+  for (int d = 7; d >= 0; d--) if (!present[d]) pp.blk0[d] = nb + 1;
   pp.seq = seq; pp.counter = counter; pp.err = err;
   pp.mSW = mixed[0]; pp.mSE = mixed[1]; pp.mNE = mixed[2]; pp.mNW = mixed[3];
-  const int n = L->nx > L->ny ? L->nx : L->ny;
-  const dim3 grid((n + 63) / 64, L->nz, 8);
-  if (unpack) hipLaunchKernelGGL(k_halo_wait_unpack, grid, dim3(64), 0, st, *L, a, hb, pp);
-  else hipLaunchKernelGGL(k_halo_push, grid, dim3(64), 0, st, *L, a, hb, pp);
+  if (nb == 0) return;
+  if (unpack) hipLaunchKernelGGL(k_halo_wait_unpack, dim3(nb), dim3(256), 0, st, *L, a, hb, pp);
+  else hipLaunchKernelGGL(k_halo_push, dim3(nb), dim3(256), 0, st, *L, a, hb, pp);
 }
 void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
