@@ -37,8 +37,8 @@ void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, S
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
-void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, unsigned long long *const *, const int *, unsigned long long,
-                   unsigned int *, int *, int, const int *);
+void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, double *const *, unsigned long long *const *,
+                   unsigned long long *const *, const int *, unsigned long long, unsigned int *, int *, const int *);
 void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
 void mgxk_convert8(hipStream_t, const LevView *, const double *);
@@ -254,9 +254,8 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
       lbuf[d] = S.p2p_slab + L.p2p_off[d][par];
       lflag[d] = S.p2p_flags + (li * 8 + d) * 2 + par;
     }
-    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, rflag, present, seq, S.p2p_counter, S.p2p_err, 0, m);
-    mgxk_halo_p2p(S.stream, &L.v, a, lbuf, lflag, present, seq, S.p2p_counter, S.p2p_err, 1, m);  // mixed corners included
-    S.n_launch += 2; S.n_p2p++;
+    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, lbuf, rflag, lflag, present, seq, S.p2p_counter, S.p2p_err, m);  // push, wait, unpack, mixed corners
+    S.n_launch++; S.n_p2p++;
   } else if (n) {
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf, present, 0); S.n_launch++;       // all edges + corners, one launch
     CHK(exchange(n, peer, sb, rb, cnt));

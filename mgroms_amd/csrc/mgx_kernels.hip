@@ -1017,10 +1017,10 @@ __global__ void k_halo_pack_all(LevView L, double *__restrict__ a, HaloBufs hb, 
 }
 
 // ---- peer-to-peer halo transport (xGMI, no host in the loop) --------------------------------------------------
-// Push: the pack kernel writes the edges straight into the NEIGHBOURS' receive buffers (fine-grained device memory
-// opened through hipIpc), every block fences at system scope, and the last block to finish raises the sequence
-// number in each neighbour's flag.  Unpack: a block spins (bounded) on the LOCAL flag of its direction, then copies
-// the received edge into the halo.  Receive buffers alternate by the parity of the per-level sequence number:
+// Push: edges are written straight into the NEIGHBOURS' receive buffers (fine-grained device memory opened through
+// hipIpc), every block fences at system scope, and the last block to finish raises the sequence number in each
+// neighbour's flag.  Unpack: a block spins (bounded) on the LOCAL flag of its direction, then copies the received edge
+// into the halo.  Receive buffers alternate by the parity of the per-level sequence number:
 // a rank cannot push exchange n+2 before it has unpacked n+1, which its neighbour pushed after unpacking n.
 struct HaloP2P {
   unsigned long long *flag[8];  // push: the neighbour's flag to raise; unpack: the local flag to wait on
@@ -1042,29 +1042,29 @@ __device__ __forceinline__ bool halo_item(const LevView &L, const HaloP2P &pp, i
   k = w / n; q = w - k * n;
   return halo_elem(L, dir, q, k, unpack, e, t);
 }
-__global__ __launch_bounds__(256) void k_halo_push(LevView L, const double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
+// One launch per halo fill: every block first pushes its part of direction d into the neighbour's receive buffer, the last
+// block to finish pushing raises the neighbours' flags, then every block waits (bounded) on the LOCAL flag of its
+// direction and unpacks the same part of the edge it received.  The grid is a few hundred blocks (compact, present
+// directions only), far below what the GPU keeps resident, so a block that spins never keeps a pushing block from
+// starting; should that ever fail the 5 s time-out turns it into an error, not a hang.
+struct HaloXchg { double *rbuf[8]; double *lbuf[8]; unsigned long long *rflag[8]; unsigned long long *lflag[8]; int present[8]; };
+__global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__restrict__ a, HaloXchg hx, HaloP2P pp) {
   int dir, q, k; long long e, t;
-  if (halo_item(L, pp, 0, dir, q, k, e, t)) hb.b[dir][t] = a[e];
+  if (halo_item(L, pp, 0, dir, q, k, e, t)) hx.rbuf[dir][t] = a[e];
   __threadfence_system();  // this wave's remote writes are performed before the block reports in
   __syncthreads();
+  __shared__ int ok;
   if (threadIdx.x == 0) {
     if (__hip_atomic_fetch_add(pp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(pp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       for (int d = 0; d < 8; d++)
-        if (hb.present[d]) __hip_atomic_store(pp.flag[d], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (hx.present[d]) __hip_atomic_store(hx.rflag[d], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-  }
-}
-__global__ __launch_bounds__(256) void k_halo_wait_unpack(LevView L, double *__restrict__ a, HaloBufs hb, HaloP2P pp) {
-  int dir, q, k; long long e, t;
-  const bool mine = halo_item(L, pp, 1, dir, q, k, e, t);  // dir is block-uniform
-  __shared__ int ok;
-  if (threadIdx.x == 0) {
     ok = 0;
     const long long t0 = wall_clock64();
     while (true) {
-      if (__hip_atomic_load(pp.flag[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= pp.seq) { ok = 1; break; }
+      if (__hip_atomic_load(hx.lflag[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= pp.seq) { ok = 1; break; }
       if (wall_clock64() - t0 > 500000000LL) break;  // 5 s of the 100 MHz constant clock: the neighbour is gone
       __builtin_amdgcn_s_sleep(4);
     }
@@ -1072,8 +1072,8 @@ __global__ __launch_bounds__(256) void k_halo_wait_unpack(LevView L, double *__r
   __syncthreads();
   if (!ok) { if (threadIdx.x == 0) *pp.err = 1; return; }
   __threadfence_system();
-  if (!mine) return;
-  const double v = __builtin_nontemporal_load(hb.b[dir] + t);
+  if (!halo_item(L, pp, 1, dir, q, k, e, t)) return;
+  const double v = __builtin_nontemporal_load(hx.lbuf[dir] + t);
   a[e] = v;
   // mixed corners (mg_mpi_exchange.f90:720-743): the corner next to a physical side mirrors the edge halo cell that was
   // just received -- written here by the thread that unpacked that cell instead of a separate launch
@@ -1552,24 +1552,23 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
   const int n = L->nx > L->ny ? L->nx : L->ny;
   hipLaunchKernelGGL(k_halo_pack_all, dim3((n + 63) / 64, L->nz, 8), dim3(64), 0, st, *L, a, hb, unpack);
 }
-void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *bufs, unsigned long long *const *flags, const int *present,
-                   unsigned long long seq, unsigned int *counter, int *err, int unpack, const int *mixed) {
-  HaloBufs hb; HaloP2P pp;
+void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *rbuf, double *const *lbuf, unsigned long long *const *rflag,
+                   unsigned long long *const *lflag, const int *present, unsigned long long seq, unsigned int *counter, int *err, const int *mixed) {
+  HaloXchg hx; HaloP2P pp;
   int nb = 0;
   for (int d = 0; d < 8; d++) {
-    hb.b[d] = bufs[d]; hb.present[d] = present[d]; pp.flag[d] = flags[d];
+    hx.rbuf[d] = rbuf[d]; hx.lbuf[d] = lbuf[d]; hx.rflag[d] = rflag[d]; hx.lflag[d] = lflag[d]; hx.present[d] = present[d];
+    pp.flag[d] = nullptr;
     pp.blk0[d] = nb;
     if (present[d]) nb += (L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1)) + 255) / 256;
   }
   pp.blk0[8] = nb;
-  // absent directions get an empty range; halo_item picks the LAST d with blk0[d] <= b, so a block lands on the present
-  // direction whose range contains it only if later absent ones do not share its start: push them past the end
+  // halo_item picks the LAST d with blk0[d] <= block index: absent directions are moved past the end
   for (int d = 7; d >= 0; d--) if (!present[d]) pp.blk0[d] = nb + 1;
   pp.seq = seq; pp.counter = counter; pp.err = err;
   pp.mSW = mixed[0]; pp.mSE = mixed[1]; pp.mNE = mixed[2]; pp.mNW = mixed[3];
   if (nb == 0) return;
-  if (unpack) hipLaunchKernelGGL(k_halo_wait_unpack, dim3(nb), dim3(256), 0, st, *L, a, hb, pp);
-  else hipLaunchKernelGGL(k_halo_push, dim3(nb), dim3(256), 0, st, *L, a, hb, pp);
+  hipLaunchKernelGGL(k_halo_exchange, dim3(nb), dim3(256), 0, st, *L, a, hx, pp);
 }
 void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
