@@ -136,8 +136,8 @@ int mgx_counters(long long *out);
 /* ---- peer-to-peer halo transport (replaces the MPI_Isend/MPI_Irecv/MPI_Waitall of fill_halo_3D[_relax],
  * mg_mpi_exchange.f90:504-718, for the p/b/r halos of the cycle) ----
  * Ranks of one node write their edges straight into the neighbours' receive buffers over xGMI (device memory shared
- * through hipIpc) and raise a flag there; the receiver's unpack kernel waits on its local flag.  No host step, no
- * callback.  Set-up is collective: every rank calls mgx_p2p_prepare (after mgx_init), the handle blobs
+ * through hipIpc) and raise a flag there; the receiver waits on its local flag and unpacks -- one kernel per halo fill,
+ * no host step, no callback.  Set-up is collective: every rank calls mgx_p2p_prepare (after mgx_init), the handle blobs
  * (mgx_p2p_handle_bytes() each) are all-gathered in rank order by the caller, every rank calls mgx_p2p_connect with
  * the concatenation.  mgx_set_option("p2p", 0|1) switches between this transport and the exchange callback (all
  * ranks together).  A neighbour that never shows up makes the next synchronising call fail (5 s device time-out). */
