@@ -846,6 +846,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (par) p = *par; else { mgx_params_default(&p); CHK(mgx_read_namelist(nullptr, &p)); }
   CHK(apply_params(p));
   if (nx < 2 || ny < 2 || nz < 2 || (nx & 1) || (ny & 1) || (nz & 1)) return fail("nx,ny,nz must be even and >= 2 (got %d %d %d)", nx, ny, nz);
+  if (npx < 1 || npy < 1 || (npx & (npx - 1)) || (npy & (npy - 1))) return fail("the process grid must be powers of two in both directions (got %d x %d)", npx, npy);
   if (rank < 0 || rank >= npx * npy) return fail("rank %d outside the %d x %d process grid", rank, npx, npy);
   S.npx = npx; S.npy = npy; S.nranks = npx * npy; S.rank = rank; S.pi = rank % npx; S.pj = rank / npx;
   S.nlevs = find_grid_levels(npx, npy, nx, ny, nz);

@@ -410,6 +410,10 @@ def test_error_behaviour(mg):
         mg.nhydro_init(15, 16, 8, 1, 1, 0, mg.nhydro.default_params())  # odd size
     with pytest.raises(MgxError):
         mg.nhydro_init(16, 16, 8, 1, 1, 0, mg.nhydro.default_params(interp_type="linear", restrict_type="linear"))
+    with pytest.raises(MgxError):
+        mg.nhydro_init(16, 16, 8, 3, 1, 0, mg.nhydro.default_params())  # process grid not a power of two
+    with pytest.raises(MgxError):
+        mg.nhydro_init(20, 16, 16, 1, 1, 0, mg.nhydro.default_params())  # 20 -> 10 -> 5: an odd local size on level 3
     mg.nhydro_init(16, 16, 8, 1, 1, 0, mg.nhydro.default_params())
     with pytest.raises(MgxError):
         mg.relax(9, 1)
