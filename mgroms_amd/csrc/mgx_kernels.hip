@@ -1029,28 +1029,33 @@ struct HaloP2P {
   int *err;                     // host-mapped error word: 1 = a wait timed out
   int mSW, mSE, mNE, mNW;       // unpack: mixed corners (one side physical, the other a neighbour), see k_halo_mixed_corners
   int blk0[9];                  // compact 1-D grid: blocks blk0[d] .. blk0[d+1]-1 serve direction d (empty when absent)
+  int ipt;                      // items per thread (> 1 only for very long edges: keeps the grid within what is resident)
 };
 // item w of direction d is buffer element w = k*n_d + q: consecutive lanes = consecutive buffer elements
-__device__ __forceinline__ bool halo_item(const LevView &L, const HaloP2P &pp, int unpack, int &dir, int &q, int &k, long long &e, long long &t) {
-  const int b = blockIdx.x;
-  dir = 0;
+__device__ __forceinline__ int halo_dir(const HaloP2P &pp) {
+  int dir = 0;
 #pragma unroll
-  for (int d = 1; d < 8; d++) if (b >= pp.blk0[d]) dir = d;
+  for (int d = 1; d < 8; d++) if ((int)blockIdx.x >= pp.blk0[d]) dir = d;
+  return dir;
+}
+__device__ __forceinline__ bool halo_item(const LevView &L, const HaloP2P &pp, int dir, int r, int unpack, int &q, int &k, long long &e, long long &t) {
   const int n = (dir == 0 || dir == 2) ? L.nx : ((dir == 1 || dir == 3) ? L.ny : 1);
-  const int w = (b - pp.blk0[dir]) * blockDim.x + threadIdx.x;
+  const int w = (((int)blockIdx.x - pp.blk0[dir]) * pp.ipt + r) * blockDim.x + threadIdx.x;
   if (w >= n * L.nz) return false;
   k = w / n; q = w - k * n;
   return halo_elem(L, dir, q, k, unpack, e, t);
 }
 // One launch per halo fill: every block first pushes its part of direction d into the neighbour's receive buffer, the last
 // block to finish pushing raises the neighbours' flags, then every block waits (bounded) on the LOCAL flag of its
-// direction and unpacks the same part of the edge it received.  The grid is a few hundred blocks (compact, present
-// directions only), far below what the GPU keeps resident, so a block that spins never keeps a pushing block from
-// starting; should that ever fail the 5 s time-out turns it into an error, not a hang.
+// direction and unpacks the same part of the edge it received.  The grid is at most 1024 blocks (compact, present
+// directions only, several items per thread on very long edges), well below what the GPU keeps resident, so a block
+// that spins never keeps a pushing block from starting; should that ever fail the 5 s time-out turns it into an error.
 struct HaloXchg { double *rbuf[8]; double *lbuf[8]; unsigned long long *rflag[8]; unsigned long long *lflag[8]; int present[8]; };
 __global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__restrict__ a, HaloXchg hx, HaloP2P pp) {
-  int dir, q, k; long long e, t;
-  if (halo_item(L, pp, 0, dir, q, k, e, t)) hx.rbuf[dir][t] = a[e];
+  const int dir = halo_dir(pp);  // block-uniform
+  int q, k; long long e, t;
+  for (int r = 0; r < pp.ipt; r++)
+    if (halo_item(L, pp, dir, r, 0, q, k, e, t)) hx.rbuf[dir][t] = a[e];
   __threadfence_system();  // this wave's remote writes are performed before the block reports in
   __syncthreads();
   __shared__ int ok;
@@ -1072,17 +1077,19 @@ __global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__rest
   __syncthreads();
   if (!ok) { if (threadIdx.x == 0) *pp.err = 1; return; }
   __threadfence_system();
-  if (!halo_item(L, pp, 1, dir, q, k, e, t)) return;
-  const double v = __builtin_nontemporal_load(hx.lbuf[dir] + t);
-  a[e] = v;
-  // mixed corners (mg_mpi_exchange.f90:720-743): the corner next to a physical side mirrors the edge halo cell that was
-  // just received -- written here by the thread that unpacked that cell instead of a separate launch
   const int nx = L.nx, ny = L.ny;
-  const long long ro = (long long)k * L.RS, W0 = ro, E0 = (long long)(nx + 1) * L.plane + ro;
-  if (dir == 0) { if (q == 0 && pp.mSW == 1) a[W0 + jpos(L, 0)] = v; if (q == nx - 1 && pp.mSE == 1) a[E0 + jpos(L, 0)] = v; }
-  else if (dir == 2) { if (q == 0 && pp.mNW == 1) a[W0 + jpos(L, ny + 1)] = v; if (q == nx - 1 && pp.mNE == 1) a[E0 + jpos(L, ny + 1)] = v; }
-  else if (dir == 3) { if (q == 0 && pp.mSW == 2) a[W0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNW == 2) a[W0 + jpos(L, ny + 1)] = v; }
-  else if (dir == 1) { if (q == 0 && pp.mSE == 2) a[E0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNE == 2) a[E0 + jpos(L, ny + 1)] = v; }
+  for (int r = 0; r < pp.ipt; r++) {
+    if (!halo_item(L, pp, dir, r, 1, q, k, e, t)) continue;
+    const double v = __builtin_nontemporal_load(hx.lbuf[dir] + t);
+    a[e] = v;
+    // mixed corners (mg_mpi_exchange.f90:720-743): the corner next to a physical side mirrors the edge halo cell that was
+    // just received -- written here by the thread that unpacked that cell instead of a separate launch
+    const long long ro = (long long)k * L.RS, W0 = ro, E0 = (long long)(nx + 1) * L.plane + ro;
+    if (dir == 0) { if (q == 0 && pp.mSW == 1) a[W0 + jpos(L, 0)] = v; if (q == nx - 1 && pp.mSE == 1) a[E0 + jpos(L, 0)] = v; }
+    else if (dir == 2) { if (q == 0 && pp.mNW == 1) a[W0 + jpos(L, ny + 1)] = v; if (q == nx - 1 && pp.mNE == 1) a[E0 + jpos(L, ny + 1)] = v; }
+    else if (dir == 3) { if (q == 0 && pp.mSW == 2) a[W0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNW == 2) a[W0 + jpos(L, ny + 1)] = v; }
+    else if (dir == 1) { if (q == 0 && pp.mSE == 2) a[E0 + jpos(L, 0)] = v; if (q == ny - 1 && pp.mNE == 2) a[E0 + jpos(L, ny + 1)] = v; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1555,12 +1562,20 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
 void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *rbuf, double *const *lbuf, unsigned long long *const *rflag,
                    unsigned long long *const *lflag, const int *present, unsigned long long seq, unsigned int *counter, int *err, const int *mixed) {
   HaloXchg hx; HaloP2P pp;
+  // every block both pushes and waits, so all of them must be resident together: at most 1024 blocks (4096 light waves of
+  // the 8192+ the chip holds); longer edges give each thread several items
+  long long items = 0;
+  for (int d = 0; d < 8; d++) if (present[d]) items += (long long)L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1));
+  pp.ipt = (int)((items + 256LL * 1000 - 1) / (256LL * 1000));
+  static const int ipt_min = getenv("MGX_P2P_IPT") ? atoi(getenv("MGX_P2P_IPT")) : 1;  // test hook for the multi-item path
+  if (pp.ipt < ipt_min) pp.ipt = ipt_min;
+  const int per = 256 * pp.ipt;
   int nb = 0;
   for (int d = 0; d < 8; d++) {
     hx.rbuf[d] = rbuf[d]; hx.lbuf[d] = lbuf[d]; hx.rflag[d] = rflag[d]; hx.lflag[d] = lflag[d]; hx.present[d] = present[d];
     pp.flag[d] = nullptr;
     pp.blk0[d] = nb;
-    if (present[d]) nb += (L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1)) + 255) / 256;
+    if (present[d]) nb += (L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1)) + per - 1) / per;
   }
   pp.blk0[8] = nb;
   // halo_item picks the LAST d with blk0[d] <= block index: absent directions are moved past the end

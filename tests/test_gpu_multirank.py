@@ -53,6 +53,13 @@ def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
         assert f"rank {r} ok" in out
 
 
+def test_multirank_long_edge_path(monkeypatch):
+    """Exchange kernel with several items per thread (what very long edges use to keep the grid resident), forced here
+    through the MGX_P2P_IPT test hook on the 2x2 case with gathers."""
+    monkeypatch.setenv("MGX_P2P_IPT", "3")
+    test_multirank_solve(2, 2, 32, 32, 16, 8, "FC")
+
+
 @pytest.mark.parametrize("transport", ["mpi-hooks", "p2p"])
 def test_fortran_mpi_harness(tmp_path, transport):
     """The reference's parallel driver shape (Fortran + MPI, fortran/mg_testseamount_gpu_mpi.f90) on 2x2 ranks over
