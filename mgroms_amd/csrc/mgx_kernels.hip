@@ -1047,9 +1047,9 @@ __device__ __forceinline__ bool halo_item(const LevView &L, const HaloP2P &pp, i
 }
 // One launch per halo fill: every block first pushes its part of direction d into the neighbour's receive buffer, the last
 // block to finish pushing raises the neighbours' flags, then every block waits (bounded) on the LOCAL flag of its
-// direction and unpacks the same part of the edge it received.  The grid is at most 1024 blocks (compact, present
-// directions only, several items per thread on very long edges), well below what the GPU keeps resident, so a block
-// that spins never keeps a pushing block from starting; should that ever fail the 5 s time-out turns it into an error.
+// direction and unpacks the same part of the edge it received.  The grid is at most ~128 blocks (compact, present
+// directions only, several items per thread on long edges), well below what the GPU keeps resident, so a block that
+// spins never keeps a pushing block from starting; should that ever fail the 5 s time-out turns it into an error.
 struct HaloXchg { double *rbuf[8]; double *lbuf[8]; unsigned long long *rflag[8]; unsigned long long *lflag[8]; int present[8]; };
 __global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__restrict__ a, HaloXchg hx, HaloP2P pp) {
   const int dir = halo_dir(pp);  // block-uniform
@@ -1192,13 +1192,13 @@ __global__ void k_gather_place_wait(LevView C, double *__restrict__ dstjs, const
     __threadfence_system();
   }
   const long long n = (long long)C.nz * nyc * nxc;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int j = 1 + (int)(t % nyc);
-  const long long ik = t / nyc;
-  const int k = (int)(ik % C.nz), i = 1 + (int)(ik / C.nz);
-  const double v = __builtin_nontemporal_load(blk + ((long long)i * C.nz + k) * (nyc + 2) + j);
-  dstjs[(long long)(i + l * nxc) * C.plane + (long long)k * C.RS + jpos(C, j + m * nyc)] = v;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int j = 1 + (int)(t % nyc);
+    const long long ik = t / nyc;
+    const int k = (int)(ik % C.nz), i = 1 + (int)(ik / C.nz);
+    const double v = __builtin_nontemporal_load(blk + ((long long)i * C.nz + k) * (nyc + 2) + j);
+    dstjs[(long long)(i + l * nxc) * C.plane + (long long)k * C.RS + jpos(C, j + m * nyc)] = v;
+  }
 }
 // split (mg_gather.f90:177-220): own quadrant of the gathered p, halo included, into the small JS block
 __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, double *__restrict__ dst, int l, int m) {
@@ -1562,11 +1562,14 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
 void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *rbuf, double *const *lbuf, unsigned long long *const *rflag,
                    unsigned long long *const *lflag, const int *present, unsigned long long seq, unsigned int *counter, int *err, const int *mixed) {
   HaloXchg hx; HaloP2P pp;
-  // every block both pushes and waits, so all of them must be resident together: at most 1024 blocks (4096 light waves of
-  // the 8192+ the chip holds); longer edges give each thread several items
+  // Every block both pushes and waits, so all of them must be resident together, and a waiting wave, however light, keeps
+  // a 512-VGPR smoother wave off its SIMD: harmless when the GPU belongs to one rank (the smoother is behind us in the
+  // stream), fatal when several ranks share one GPU as in the tests (the neighbour's smoother would never start).  So the
+  // grid is kept small -- at most 128 blocks = 512 of the 1024 SIMDs -- and longer edges give each thread several items.
+  static const int maxblk = getenv("MGX_P2P_MAXBLK") ? atoi(getenv("MGX_P2P_MAXBLK")) : 128;
   long long items = 0;
   for (int d = 0; d < 8; d++) if (present[d]) items += (long long)L->nz * ((d == 0 || d == 2) ? L->nx : ((d == 1 || d == 3) ? L->ny : 1));
-  pp.ipt = (int)((items + 256LL * 1000 - 1) / (256LL * 1000));
+  pp.ipt = (int)((items + 256LL * maxblk - 1) / (256LL * maxblk)) + 1;  // +1: per-direction round-up never exceeds maxblk
   static const int ipt_min = getenv("MGX_P2P_IPT") ? atoi(getenv("MGX_P2P_IPT")) : 1;  // test hook for the multi-item path
   if (pp.ipt < ipt_min) pp.ipt = ipt_min;
   const int per = 256 * pp.ipt;
@@ -1615,7 +1618,9 @@ void mgxk_gather_push(hipStream_t st, const LevView *Cs, const double *js, doubl
 void mgxk_gather_place_wait(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m,
                             unsigned long long *flag, unsigned long long seq, int *err) {
   const long long n = (long long)C->nz * nyc * nxc;
-  hipLaunchKernelGGL(k_gather_place_wait, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *C, dstjs, blk, nxc, nyc, l, m, flag, seq, err);
+  long long nb = (n + 255) / 256;
+  if (flag && nb > 128) nb = 128;  // blocks that may spin stay few (see mgxk_halo_p2p)
+  hipLaunchKernelGGL(k_gather_place_wait, dim3((unsigned)nb), dim3(256), 0, st, *C, dstjs, blk, nxc, nyc, l, m, flag, seq, err);
 }
 void mgxk_split(hipStream_t st, const LevView *C, const LevView *Cs, const double *pc, double *dst, int l, int m) {
   const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
