@@ -222,7 +222,8 @@ def main():
     if rank == 0:
         scale = npx * npy
         out = {
-            "metric": "vcycles_per_sec", "value": args.steps / dt * scale, "unit": "Vcycle(1)/s per 512x512x64 block-equivalent",
+            "metric": "V-cycles/sec, seamount 512x512x64 (fine-grid smoother HBM GB/s and % of 8 TB/s: see roofline)",
+            "value": args.steps / dt * scale, "unit": "V-cycles/s (x number of 512x512x64 blocks when N>1: weak scaling)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"seamount {nx * npx}x{ny * npy}x{nz} ({npx}x{npy} ranks of {nx}x{ny}x{nz}), "
