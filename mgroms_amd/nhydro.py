@@ -66,7 +66,12 @@ def nhydro_init(nx, ny, nz, npxg=1, npyg=1, rank=0, params=None, comm=None):
     check(lib().mgx_init(nx, ny, nz, npxg, npyg, rank, None if params is None else C.byref(params)))
     _state["dims"] = (nx, ny, nz)
     if comm is not None and comm.p2p and npxg * npyg > 1:
-        comm.connect_p2p()
+        try:
+            comm.connect_p2p()
+        except Exception as e:  # the halo pushes are an optimisation: anything unexpected leaves the callback transport in charge
+            comm.p2p_active = False
+            comm.p2p_error = f"connect_p2p raised {e!r}"
+            lib().mgx_set_option(b"p2p", 0)
 
 
 def nhydro_matrices(dx, dy, zeta, h, rmask=None, hc=0.0, theta_b=0.0, theta_s=0.0):
