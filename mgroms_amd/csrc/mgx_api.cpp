@@ -33,7 +33,7 @@ int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
-void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides);
+void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
@@ -454,13 +454,16 @@ int residual(int lev, double *res) {
 }
 
 // mg_intergrids.f90:16-72
-int fine2coarse(int lev) {
+int fine2coarse(int lev, bool dup_r = false) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0}, none = {0, 0, 0, 0};
+  bool fused = false;
   if (!C.gather) {
-    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc); S.n_launch++;
+    // closed level: the kernel also zeroes p_c and, for Fcycle, duplicates b_c into r_c (whole arrays through the mirrors)
+    fused = phc.S && phc.E && phc.N && phc.W;
+    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc, fused && dup_r ? C.v.r : nullptr, fused ? C.v.p : nullptr); S.n_launch++;
   } else {
-    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none); S.n_launch++;
+    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none, nullptr, nullptr); S.n_launch++;
     const int Ng = C.nz * (C.vs.ny + 2) * (C.vs.nx + 2);
     if (S.p2p_on) {  // gather_3D (mg_gather.f90:95-174) as pushes into the members' gather buffers
       const unsigned long long seq = ++C.p2p_gseq;
@@ -492,7 +495,10 @@ int fine2coarse(int lev) {
   }
   // b's halo is not read by relax/residual either: physical mirrors are in place, neighbour exchange deferred
   if (S.exact_halos || C.gather) CHK(fill_halo_js(C, C.v.b, !C.gather)); else C.b_halo_stale = true;
-  HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
+  if (!fused) {
+    HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
+    if (dup_r) HIPCHK(hipMemcpyAsync(C.v.r, C.v.b, C.n3js * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+  }
   return 0;
 }
 
@@ -547,9 +553,7 @@ int vcycle2(int lev1, int lev2) {
 int fcycle() {
   TicScope ts(1, "Fcycle");  // mg_solvers.f90:108
   for (int lev = 1; lev <= S.nlevs - 1; lev++) {
-    CHK(fine2coarse(lev));
-    Level &C = S.lev[lev];
-    HIPCHK(hipMemcpyAsync(C.v.r, C.v.b, C.n3js * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) {

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
 // `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph, int stream) {
+__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph, int stream, double *__restrict__ dup, double *__restrict__ zero) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (j2 > C.ny || i2 > C.nx) return;
@@ -877,6 +877,10 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
                    + ld_rt(x + o0 + r1 + po, stream) + ld_rt(x + o1 + r1 + po, stream) + ld_rt(x + o0 + r1 + pe, stream) + ld_rt(x + o1 + r1 + pe, stream);
     dst[oc + (long long)(k2 - 1) * C.RS] = z;
     mirror_store(C, dst, (long long)(k2 - 1) * C.RS, j2, i2, jpos(C, j2), z, ph);
+    // closed levels only (the mirrors then reach every halo cell): r_c = b_c of Fcycle (mg_solvers.f90:113) and p_c = 0
+    // (mg_intergrids.f90:70) written here instead of a copy and a memset launch
+    if (dup) { dup[oc + (long long)(k2 - 1) * C.RS] = z; mirror_store(C, dup, (long long)(k2 - 1) * C.RS, j2, i2, jpos(C, j2), z, ph); }
+    if (zero) { zero[oc + (long long)(k2 - 1) * C.RS] = 0.0; mirror_store(C, zero, (long long)(k2 - 1) * C.RS, j2, i2, jpos(C, j2), 0.0, ph); }
   }
 }
 
@@ -1537,8 +1541,8 @@ void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *parti
   hipLaunchKernelGGL(k_sumsq, grd, blk, 0, st, *L, a, partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }
-void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph) {
-  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F));
+void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {
+  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero);
 }
 void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph) {
   const int by = C->nz >= 4 ? 4 : C->nz;
