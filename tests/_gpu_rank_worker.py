@@ -90,6 +90,16 @@ def main():
         assert n2 == n and np.array_equal(hist2, hist) and np.array_equal(mg.grid(1).p, p_first)
         assert nhydro.counters()["p2p_exchanges"] == c["p2p_exchanges"]
         comm.set_p2p(True)
+    # src/old_tests/mg_testhalo.f90:75-92: fill p with the rank number, fill the halo: every halo plane holds the neighbour's
+    # rank, or the own one across a physical boundary
+    g1 = mg.grid(1)
+    g1.set("p", np.full(g1._shape("p"), float(rank)))
+    mg.fill_halo(1, "p")
+    ph = g1.get("p")
+    nbr = g1.neighb
+    want = lambda q: float(q if q >= 0 else rank)
+    assert np.all(ph[1:-1, 0, :] == want(nbr[0])) and np.all(ph[-1, 1:-1, :] == want(nbr[1])), rank
+    assert np.all(ph[1:-1, -1, :] == want(nbr[2])) and np.all(ph[0, 1:-1, :] == want(nbr[3])), rank
     stamp("checks")
     mg.nhydro_clean()
     dist.barrier()

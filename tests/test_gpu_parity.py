@@ -169,6 +169,24 @@ def test_transfers_bitwise(mg):
         assert np.array_equal(g1.get("p"), o.field("p", 1))
 
 
+def test_intergrid_properties(mg):
+    # the checks of the reference's unit program src/old_tests/mg_testintergrids.f90:84-128, through the C ABI and without the
+    # oracle: restricting a constant gives 8x the constant, the prolongation reproduces a linear ramp away from the boundaries
+    _setup(mg, 32, 32, 16)
+    g1, g2 = mg.grid(1), mg.grid(2)
+    g1.set("r", np.full(g1._shape("r"), 2.5))
+    mg.fine2coarse(1)
+    assert np.all(g2.get("b")[1:-1, 1:-1, :] == 20.0) and np.all(g2.get("p") == 0.0)
+    ic, jc, kc = np.meshgrid(np.arange(18), np.arange(18), np.arange(1, 9), indexing="ij")
+    g2.set("p", 3.0 * ic + 5.0 * jc + 7.0 * kc)
+    g1.set("p", np.zeros(g1._shape("p")))
+    mg.coarse2fine(1)
+    i, j, k = np.meshgrid(np.arange(34), np.arange(34), np.arange(1, 17), indexing="ij")
+    exact = 3.0 * ((i + 0.5) / 2.0) + 5.0 * ((j + 0.5) / 2.0) + 7.0 * ((k + 0.5) / 2.0)
+    inner = (slice(1, 33), slice(1, 33), slice(1, 15))
+    assert np.allclose(g1.get("p")[inner], exact[inner], rtol=0, atol=1e-12)
+
+
 def test_compute_rhs_and_correct_uvw(mg):
     nx, ny, nz = 32, 16, 8
     o = _setup(mg, nx, ny, nz, solver_maxiter=3)

@@ -152,3 +152,42 @@ def test_bmask_branch_converges_and_is_decomposition_independent():
     for r in range(4):
         pi, pj = r % 2, r // 2
         assert np.array_equal(many.field("p", 1, r)[1:-1, 1:-1, :], p1[1 + pi * 16:17 + pi * 16, 1 + pj * 16:17 + pj * 16, :]), r
+
+
+def test_intergrid_properties_like_the_reference_unit_programs():
+    """The checks of the reference's (stale) unit program src/old_tests/mg_testintergrids.f90:84-128, on the oracle:
+    restricting a constant gives 8x the constant (fine2coarse sums 8 cells, no 1/8: mg_intergrids.f90:139-162), and the
+    tri-linear prolongation reproduces a linear ramp away from the boundaries (weights (27,9,9,9,3,3,3,1)/64)."""
+    o = make_seamount(32, 32, 16, relax_method="FC")
+    o.field("r", 1)[...] = 2.5
+    o.fine2coarse(1)
+    assert np.all(o.field("b", 2)[1:-1, 1:-1, :] == 20.0)
+    assert np.all(o.field("p", 2) == 0.0)  # p_c = 0 over the whole array (mg_intergrids.f90:70)
+    # linear ramp in i, j and k on the coarse grid; cell centres: coarse index c <-> fine indices 2c-1, 2c at +-1/4
+    pc = o.field("p", 2)
+    nxc, nyc, nzc = pc.shape[0] - 2, pc.shape[1] - 2, pc.shape[2]
+    ic, jc, kc = np.meshgrid(np.arange(nxc + 2), np.arange(nyc + 2), np.arange(1, nzc + 1), indexing="ij")
+    pc[...] = 3.0 * ic + 5.0 * jc + 7.0 * kc
+    o.field("p", 1)[...] = 0.0
+    o.coarse2fine(1)
+    pf = o.field("p", 1)  # p_f = 0 + interpolant
+    i, j, k = np.meshgrid(np.arange(34), np.arange(34), np.arange(1, 17), indexing="ij")
+    exact = 3.0 * ((i + 0.5) / 2.0) + 5.0 * ((j + 0.5) / 2.0) + 7.0 * ((k + 0.5) / 2.0)
+    inner = (slice(1, 33), slice(1, 33), slice(1, 15))  # k = 2..15: the bottom and top rows use their own weights
+    assert np.allclose(pf[inner], exact[inner], rtol=0, atol=1e-12)
+
+
+def test_halo_fill_carries_the_neighbour_rank_like_mg_testhalo():
+    """src/old_tests/mg_testhalo.f90:75-92: fill p with the rank number, fill the halo, every halo plane must hold the
+    neighbour's rank (or the own one across a physical boundary: mirror)."""
+    o = make_seamount(16, 16, 8, 2, 2, relax_method="FC")
+    for r in range(4):
+        o.field("p", 1, r)[...] = float(r)
+    o.fill_halo(1, "p")
+    for r in range(4):
+        nb = o.level_info(1, r)["neighb"]  # S, E, N, W, SW, SE, NE, NW
+        p = o.field("p", 1, r)             # [i][j][k]
+        want = lambda q: float(q if q >= 0 else r)
+        assert np.all(p[1:-1, 0, :] == want(nb[0])) and np.all(p[-1, 1:-1, :] == want(nb[1]))
+        assert np.all(p[1:-1, -1, :] == want(nb[2])) and np.all(p[0, 1:-1, :] == want(nb[3]))
+        assert np.all(p[1:-1, 1:-1, :] == float(r))
