@@ -191,3 +191,26 @@ def test_halo_fill_carries_the_neighbour_rank_like_mg_testhalo():
         assert np.all(p[1:-1, 0, :] == want(nb[0])) and np.all(p[-1, 1:-1, :] == want(nb[1]))
         assert np.all(p[1:-1, -1, :] == want(nb[2])) and np.all(p[0, 1:-1, :] == want(nb[3]))
         assert np.all(p[1:-1, 1:-1, :] == float(r))
+
+
+def test_galerkin_consistency_probe():
+    """testgalerkin (mg_solvers.f90:203-288): <xc, Ac xc> against <I xc, Af I xc> for a smooth coarse field -- the
+    rediscretised coarse operator (restriction = plain sum, geometry coarsened by define_matrices) must carry the energy of
+    the interpolated field; the reference prints the ratio and expects it near 1."""
+    o = make_seamount(32, 32, 16, relax_method="FC")
+
+    def apply(lev, x):
+        p = o.field("p", lev); p[...] = 0; p[1:-1, 1:-1, :] = x
+        o.fill_halo(lev, "p"); o.field("b", lev)[...] = 0; o.residual(lev)
+        return -o.field("r", lev)[1:-1, 1:-1, :].copy()
+
+    i, j, k = np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij")
+    xc = np.sin(np.pi * (i + 0.5) / 16) ** 2 * np.sin(np.pi * (j + 0.5) / 16) ** 2 * np.sin(np.pi * (k + 0.5) / 8)
+    ec = (xc * apply(2, xc)).sum()
+    o.field("p", 2)[...] = 0; o.field("p", 2)[1:-1, 1:-1, :] = xc; o.fill_halo(2, "p")
+    o.field("p", 1)[...] = 0
+    o.coarse2fine(1)
+    xf = o.field("p", 1)[1:-1, 1:-1, :].copy()
+    ef = (xf * apply(1, xf)).sum()
+    assert ec < 0 and ef < 0            # the operator is negative definite on fields that vanish at the boundary
+    assert 0.85 < ef / ec < 1.1, ef / ec
