@@ -214,3 +214,26 @@ def test_galerkin_consistency_probe():
     ef = (xf * apply(1, xf)).sum()
     assert ec < 0 and ef < 0            # the operator is negative definite on fields that vanish at the boundary
     assert 0.85 < ef / ec < 1.1, ef / ec
+
+
+def test_multigrid_solution_equals_a_direct_solve():
+    """The reference's Matlab cross-check (matlab/check_real_relaxation.m:30-57,406-409: direct sparse solve vs mgroms p):
+    assemble the level-1 operator column by column from the residual routine, solve A p = b densely, compare with solve_p."""
+    nx, ny, nz = 16, 16, 8
+    o = make_seamount(nx, ny, nz, relax_method="FC", solver_prec=1e-13, solver_maxiter=60)
+    o.compute_rhs()
+    b = o.field("b")[1:-1, 1:-1, :].copy()
+    n = nx * ny * nz
+    A = np.zeros((n, n))
+    for q in range(n):
+        e = np.zeros(n); e[q] = 1.0
+        p = o.field("p"); p[...] = 0; p[1:-1, 1:-1, :] = e.reshape(nx, ny, nz)
+        o.fill_halo(1, "p"); o.field("b")[...] = 0; o.residual(1)
+        A[:, q] = -o.field("r")[1:-1, 1:-1, :].ravel()
+    o.field("b")[1:-1, 1:-1, :] = b
+    direct = np.linalg.solve(A, b.ravel())
+    o.field("p")[...] = 0
+    nit, hist, _ = o.solve_p()
+    assert hist[-1] < 1e-13
+    pm = o.field("p")[1:-1, 1:-1, :].ravel()
+    assert np.abs(pm - direct).max() <= 1e-11 * np.abs(direct).max()
