@@ -1159,8 +1159,7 @@ struct GatherP2P { double *dst[4]; unsigned long long *flag[4]; int ng, me; unsi
 __global__ void k_gather_push(LevView Cs, const double *__restrict__ js, GatherP2P gp) {
   // block layout in the gather buffers: (i, k, j) with j fastest (halo included) -- lanes run along j on both sides
   const long long n = (long long)Cs.nz * (Cs.ny + 2) * (Cs.nx + 2);
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(t % (Cs.ny + 2));
     const long long ik = t / (Cs.ny + 2);
     const int k = (int)(ik % Cs.nz), i = (int)(ik / Cs.nz);
@@ -1617,7 +1616,9 @@ void mgxk_gather_push(hipStream_t st, const LevView *Cs, const double *js, doubl
   for (int q = 0; q < 4; q++) { gp.dst[q] = q < ng ? dst[q] : nullptr; gp.flag[q] = q < ng ? flags[q] : nullptr; }
   gp.ng = ng; gp.me = me; gp.seq = seq; gp.counter = counter; gp.err = err;
   const long long n = (long long)Cs->nz * (Cs->ny + 2) * (Cs->nx + 2);
-  hipLaunchKernelGGL(k_gather_push, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *Cs, js, gp);
+  long long nb = (n + 255) / 256;
+  if (nb > 256) nb = 256;  // every wave ends with a system-scope fence and every block with an atomic: few, fat blocks
+  hipLaunchKernelGGL(k_gather_push, dim3((unsigned)nb), dim3(256), 0, st, *Cs, js, gp);
 }
 void mgxk_gather_place_wait(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m,
                             unsigned long long *flag, unsigned long long seq, int *err) {
