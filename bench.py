@@ -3,7 +3,8 @@
 (BASELINE.json `metric`, configs[2]: the configuration the metric is quoted on; it fits one GPU), plus the
 HBM roofline fraction of the level-1 smoother kernel and the CPU baseline (oracle) timed on the host cores.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU; under torch.distributed.run the ranks are
+                                                        taken from the environment, from a bare shell bench.py starts them itself)
 
 A step = one Vcycle(1) (mg_solvers.f90:129) over the resident fields: ns_pre=3 sweeps + residual + restriction on
 every level down, 40 sweeps on the coarsest, prolongation + ns_post=2 sweeps up.  Inputs are synthetic (the
@@ -24,6 +25,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SMOOTHER_BYTES_PER_CELL = 88  # cA 64 + b 8 + p read 8 + p write 8, per cell per full sweep
 PGRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+# oracle/mgoracle.c against the real reference (flang -O2 + MPICH) on the SAME 8 cores of the development container, 4x2
+# ranks, seamount 512x512x64: reference time / port time.  Relates the port's number on the
+# GPU box's host cores back to the reference, which cannot travel.
+CALIBRATION = {"host": "development container, 8 cores, 4x2 (emulated) ranks, seamount 512x512x64",
+               "FC": {"solve_iteration": 0.66 / 0.711, "level1_sweep": 75.0 / 92.8, "level1_residual": 36.0 / 48.3},
+               "RB": {"solve_iteration": 0.68 / 0.750, "level1_sweep": 67.0 / 75.9, "level1_residual": 44.0 / 42.7}}
 
 
 def cpu_baseline(nx, ny, nz, method, cycles=2):
@@ -48,10 +55,29 @@ def cpu_baseline(nx, ny, nz, method, cycles=2):
     sweep = time.perf_counter() - t1
     o.close()
     return {"value": cycles / dt, "unit": "Vcycle(1)/s", "cores": cores, "kind": "port",
+            "calibration_vs_reference": CALIBRATION[method]["solve_iteration"],
+            "calibration": {"what": "reference time / port time on the same cores (1.0 = as fast as the reference)",
+                            "host": CALIBRATION["host"], **CALIBRATION[method]},
             "sample": f"{cycles} Vcycle(1) of seamount {nx}x{ny}x{nz} {method} on {npx}x{npy} emulated ranks "
                       f"({cores} OpenMP threads), after 1 untimed cycle",
             "level1_sweep_ms": sweep * 1e3,
             "level1_sweep_GBs": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / sweep / 1e9}
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as fresh child processes through
+    torch.distributed.run BEFORE this process touches the GPU (it never does), pass their output through and exit with
+    their status.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -67,7 +93,12 @@ def main():
     ap.add_argument("--no-p2p", action="store_true", help="N>1: halos through the torch.distributed callback only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
+    ap.add_argument("--no-native-rccl", action="store_true", help="N>1: torch.distributed callbacks instead of libmgx.so's own RCCL communicator")
     args = ap.parse_args()
+    if args.gpus not in PGRID:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -77,8 +108,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if args.gpus not in PGRID:
-        raise SystemExit("--gpus must be 1, 2, 4 or 8")
     if args.backend == "gloo":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -90,7 +119,7 @@ def main():
         else:
             dist.init_process_group("gloo")
         from mgroms_amd.parallel import Comm
-        comm = Comm(p2p=not args.no_p2p)
+        comm = Comm(p2p=not args.no_p2p, native=(args.backend == "nccl" and not args.no_native_rccl))
 
     import mgroms_amd as mg
     from mgroms_amd import nhydro
@@ -137,7 +166,8 @@ def main():
     # region is repeated through the RCCL callback and that number is reported.
     transport, transport_check = None, None
     if world > 1:
-        transport = "p2p: hipIpc-shared receive buffers, device-side flags (xGMI)" if comm.p2p_active else "torch.distributed P2P (RCCL)"
+        transport = comm.transport()
+        base_transport = ("RCCL, native in libmgx.so" if comm.native_active else f"torch.distributed callbacks ({args.backend})")
         if not comm.p2p_active:
             transport_check = f"p2p unavailable: {comm.p2p_error}"
         else:
@@ -152,11 +182,11 @@ def main():
             same = torch.tensor([1 if r_p2p == r_cb else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             if int(same.item()) == 1:
-                transport_check = f"residual after 2 V-cycles identical through both transports ({r_p2p:.17g})"
+                transport_check = f"residual after 2 V-cycles identical through the pushes and through {base_transport} ({r_p2p:.17g})"
                 comm.set_p2p(True)
             else:
-                transport_check = f"p2p REJECTED: residual {r_p2p:.17g} vs {r_cb:.17g} through RCCL; timing repeated through RCCL"
-                transport = "torch.distributed P2P (RCCL)"
+                transport_check = f"p2p REJECTED: residual {r_p2p:.17g} vs {r_cb:.17g} through {base_transport}; timing repeated through the latter"
+                transport = comm.transport()
                 for _ in range(args.warmup):
                     mg.Vcycle(1)
                 sync()
@@ -207,15 +237,19 @@ def main():
                    "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "note": "relax_method='RB' (reference default; parallel red-black semantics, DESIGN.md section 2)"}
 
+    # HBM traffic of the dominant kernel from the PMC counters: they cannot be collected inside this run (rocprofv3 must wrap
+    # the process, in passes of their own), so the figure is read from the committed capture of THIS command
+    # (profiles/r02_pmc_traffic.json, made by scripts/pmc_summary.py) and labelled as such
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>"
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
             if pj.get("cells") == cells and kname in pj["kernels"]:
                 traffic = pj["kernels"][kname]["hbm_bytes"]
-                traffic_src = "profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, FETCH x2 (gfx950)"
+                traffic_src = ("NOT measured in this run: profiles/r02_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "command, FETCH x2 (the guide's gfx950 correction, calibrated on an 8-B/lane read of known size)")
         except Exception:
             pass
     out = None
@@ -229,6 +263,7 @@ def main():
             "config": {"workload": f"seamount {nx * npx}x{ny * npy}x{nz} ({npx}x{npy} ranks of {nx}x{ny}x{nz}), "
                                    f"relax_method={args.method}, ns_pre=3 ns_post=2 ns_coarsest=40, cmatrix=real, interp=linear",
                        "levels": nlev_main, "step": "one Vcycle(1)", "halo_transport": transport,
+                       "native_rccl": (None if comm is None else (True if comm.native_active else f"off: {comm.native_error}")),
                        "transport_check": transport_check, "nsmall": (8 if world == 1 else args.nsmall)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

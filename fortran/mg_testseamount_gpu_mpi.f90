@@ -1,6 +1,8 @@
 !> The reference's parallel driver shape (src/mg_testseamount.f90:44-213: MPI_Init, npxg x npyg ranks, local nx x ny x nz
 !> block per rank) over module nhydro -> libmgx.so, with the MPI hooks of fortran/mgx_mpi_hooks.cpp.
-!> Usage: mpiexec -n (npx*npy) testseamount_gpu_mpi npx npy nx ny nz [p2p]      (nx,ny = LOCAL sizes)
+!> Usage: mpiexec -n (npx*npy) testseamount_gpu_mpi npx npy nx ny nz [p2p|rccl]      (nx,ny = LOCAL sizes)
+!>   p2p : the cycle's halos and gathers as device-side pushes between the ranks' GPUs (hipIpc), MPI hooks for the rest
+!>   rccl: libmgx.so's native RCCL transport instead of the MPI hooks (one GPU per rank)
 program mg_testseamount_gpu_mpi
   use iso_c_binding
   use nhydro
@@ -14,8 +16,14 @@ program mg_testseamount_gpu_mpi
      integer(c_int) function mgx_mpi_connect_p2p() bind(C, name='mgx_mpi_connect_p2p')
        import :: c_int
      end function mgx_mpi_connect_p2p
+     integer(c_int) function mgx_mpi_connect_rccl() bind(C, name='mgx_mpi_connect_rccl')
+       import :: c_int
+     end function mgx_mpi_connect_rccl
+     integer(c_int) function mgx_rccl_selftest() bind(C, name='mgx_rccl_selftest')
+       import :: c_int
+     end function mgx_rccl_selftest
   end interface
-  integer(kind=4) :: nx, ny, nz, npx, npy, i, j, rc, ierr, myrank, nprocs, pi, pj, use_p2p
+  integer(kind=4) :: nx, ny, nz, npx, npy, i, j, rc, ierr, myrank, nprocs, pi, pj, use_p2p, use_rccl
   real(kind=8) :: Lx, Ly, Htot, hc, theta_b, theta_s, x, y, x0, y0, s_loc, s_glo
   real(kind=8), dimension(:,:), pointer :: dx, dy, zeta, h, rmask
   real(kind=8), dimension(:,:,:), allocatable :: u, v, w, p, b
@@ -29,8 +37,15 @@ program mg_testseamount_gpu_mpi
   call get_command_argument(3, arg); read(arg,*) nx
   call get_command_argument(4, arg); read(arg,*) ny
   call get_command_argument(5, arg); read(arg,*) nz
-  use_p2p = 0
-  if (command_argument_count() >= 6) use_p2p = 1
+  use_p2p = 0; use_rccl = 0
+  if (command_argument_count() >= 6) then
+     call get_command_argument(6, arg)
+     if (trim(arg) == 'rccl') then
+        use_rccl = 1
+     else
+        use_p2p = 1
+     endif
+  endif
   if (npx*npy /= nprocs) then
      write(*,*) 'Error: npx*npy /= number of MPI ranks'; stop -1
   endif
@@ -38,7 +53,15 @@ program mg_testseamount_gpu_mpi
 
   nhydro_rank = myrank
   call mgx_check(mgx_mpi_install(MPI_COMM_WORLD), 'mgx_mpi_install')
+  if (use_rccl == 1) then
+     rc = mgx_mpi_connect_rccl()
+     if (myrank == 0) write(*,'(A,I2)') 'rccl_connected = ', 1 - rc
+  endif
   call nhydro_init(nx, ny, nz, npx, npy)
+  if (use_rccl == 1) then
+     rc = mgx_rccl_selftest()
+     if (myrank == 0) write(*,'(A,I2)') 'rccl_selftest_ok = ', 1 - min(rc, 1)
+  endif
   if (use_p2p == 1) then
      rc = mgx_mpi_connect_p2p()
      if (myrank == 0) write(*,'(A,I2)') 'p2p_connected = ', 1 - rc

@@ -88,7 +88,9 @@ contains
     real(kind=rp), dimension(1:nx+1,0:ny+1,1:nz), target, intent(inout) :: ua
     real(kind=rp), dimension(0:nx+1,1:ny+1,1:nz), target, intent(inout) :: va
     real(kind=rp), dimension(0:nx+1,0:ny+1,0:nz), target, intent(inout) :: wa
-    call mgx_check(mgx_solve(ua, va, wa, c_null_ptr), 'nhydro_solve')
+    ! rmaska: the memory the caller allocated as rmask(0:ny+1,0:nx+1) (mg_testseamount.f90:97,185); the reference indexes
+    ! it rmask(j,i) after `rmask => rmaska` (nhydro.f90:72, mg_compute_rhs.f90:61,110), and so does the library
+    call mgx_check(mgx_solve(ua, va, wa, c_loc(rmaska)), 'nhydro_solve')
   end subroutine nhydro_solve
 
   !--------------------------------------------------------------  (nhydro.f90:105-134)
@@ -98,7 +100,7 @@ contains
     real(kind=rp), dimension(1:nx+1,0:ny+1,1:nz), target, intent(inout) :: ua
     real(kind=rp), dimension(0:nx+1,1:ny+1,1:nz), target, intent(inout) :: va
     real(kind=rp), dimension(0:nx+1,0:ny+1,0:nz), target, intent(inout) :: wa
-    call mgx_check(mgx_check_nondivergence(ua, va, wa, c_null_ptr), 'nhydro_check_nondivergence')
+    call mgx_check(mgx_check_nondivergence(ua, va, wa, c_loc(rmaska)), 'nhydro_check_nondivergence')
   end subroutine nhydro_check_nondivergence
 
   !--------------------------------------------------------------  (nhydro.f90:137-141)

@@ -62,9 +62,15 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
  * (mg_define_matrix.f90:28-208).  rmask may be NULL (= all ones; only read when bmask). */
 int mgx_matrices(const double *dx, const double *dy, const double *zeta, const double *h, const double *rmask,
                  double hc, double theta_b, double theta_s);
-/* nhydro_solve(nx,ny,nz,rmask,u,v,w) (nhydro.f90:53-102): compute_rhs, solve_p, correct_uvw; u,v,w updated in place */
+/* nhydro_solve(nx,ny,nz,rmask,u,v,w) (nhydro.f90:53-102): compute_rhs, solve_p, correct_uvw; u,v,w updated in place.
+ * rmask = the mask of THIS call (rmaska, nhydro.f90:56,72): the same memory layout as in mgx_matrices, (0:ny+1,0:nx+1)
+ * with j fastest -- what the reference's drivers allocate (mg_testseamount.f90:97) and what compute_rhs / correct_uvw
+ * index as rmask(j,i) (mg_compute_rhs.f90:61,110; the explicit-shape dummy of nhydro_solve declares it (0:nx+1,0:ny+1),
+ * which is the same memory for the square blocks the reference is run on).  As in the reference it multiplies the w
+ * cross terms of compute_rhs whatever bmask says, and yields umask / vmask when bmask (mg_compute_rhs.f90:56-72,
+ * mg_correct_uvw.f90:51-68).  NULL = the level-1 mask of mgx_matrices when bmask, else all ones. */
 int mgx_solve(double *u, double *v, double *w, const double *rmask);
-/* nhydro_solve with the model state already on the GPU: u,v,w are DEVICE pointers (same (i,j,k) layout); no PCIe traffic.
+/* nhydro_solve with the model state already on the GPU: u,v,w (and rmask, when not NULL) are DEVICE pointers (same layouts); no PCIe traffic.
  * This is what a GPU-resident ocean model calls every time step. */
 int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *rmask);
 /* nhydro_check_nondivergence (nhydro.f90:105-134): recompute the divergence into grid(1)%b */
@@ -113,6 +119,21 @@ typedef int (*mgx_allreduce_fn)(void *ctx, double *devbuf, int n);
 typedef int (*mgx_allgather_fn)(void *ctx, const int *group, int ng, const double *sendbuf, double *recvbuf, int count);
 int mgx_set_comm(mgx_exchange_fn ex, mgx_allreduce_fn ar, mgx_allgather_fn ag, void *ctx);
 
+/* ---- native RCCL transport: the same three operations served inside libmgx.so by RCCL calls on the solver's stream
+ * (ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd per halo fill, a one-double ncclAllReduce, grouped send/recv inside
+ * the gather groups), replacing the MPI calls of mg_mpi_exchange.f90:504-718,1555-1571 and mg_gather.f90:126 with no host
+ * language in the loop.  librccl is bound at run time (the copy already in the process, else librccl.so.1).
+ * Bootstrap (collective, one rank per GPU, device selected by the caller): rank 0 obtains the id, the caller broadcasts its
+ * mgx_rccl_unique_id_bytes() bytes (MPI_Bcast, torch.distributed, ...), every rank connects; connecting installs the
+ * hooks (as mgx_set_comm would).  mgx_rccl_selftest (after mgx_init, collective): rank-coded exchange + all-reduce. */
+int mgx_rccl_unique_id_bytes(void);
+int mgx_rccl_get_unique_id(void *id_out);
+int mgx_rccl_connect(const void *id, int nranks, int rank);
+int mgx_rccl_disconnect(void);
+int mgx_rccl_selftest(void);
+/* human-readable name of the transport that carries the halos right now */
+const char *mgx_transport(void);
+
 /* HIP stream (hipStream_t) every kernel is launched on; NULL = the default stream */
 int mgx_set_stream(void *hip_stream);
 /* 0 = silent, 1 = the reference's rank-0 prints (parameter block, level table, "ite = ..: res = .. / conv = ..") */
@@ -121,7 +142,12 @@ int mgx_set_verbose(int level);
 /* Options (0/1): "warm_start" keep p between solves instead of the cold start of mg_solvers.f90:35;
  * "tictoc" per-(level,name) timers like mg_tictoc.f90 (HIP events); "exact_halos" exchange the never-read r/b halos
  * eagerly as the reference does; "verbose"; "p2p" (see below); "rb_chain" (default 1) red-black with cmatrix='real' on a
- * single-rank level: the colour passes write the next sweep's k=1 snapshot themselves, 0 = one snapshot launch per pass. */
+ * single-rank level: the colour passes write the next sweep's k=1 snapshot themselves, 0 = one snapshot launch per pass;
+ * "rb_exact" (default 0; environment MGX_RB_EXACT): relax_method='RB' with cmatrix='real' in the reference's SEQUENTIAL
+ * order (mg_relax.f90:170-186: a column reads the same-colour k=1 diagonals of plane i-1 already updated, :271-276), one
+ * launch per i-plane -- bit-identical to the reference loop, including its decomposition dependence, but launch-bound.
+ * With 0 the colour pass is parallel and reads those four values as they were before the pass (the reference's own
+ * results differ by 2.5e-6 between decompositions for the same reason; tolerance in DESIGN.md section 2). */
 int mgx_set_option(const char *name, int value);
 /* print_tictoc (mg_tictoc.f90:114-153): timer table (seconds, calls per level) to `path` (NULL = "fort.10") */
 int mgx_print_tictoc(const char *path);

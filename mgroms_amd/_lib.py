@@ -62,6 +62,12 @@ _SIGS = {
     "mgx_p2p_prepare": (C.c_int, [C.c_void_p]),
     "mgx_p2p_connect": (C.c_int, [C.c_void_p, C.c_int]),
     "mgx_p2p_exchanges": (C.c_longlong, []),
+    "mgx_rccl_unique_id_bytes": (C.c_int, []),
+    "mgx_rccl_get_unique_id": (C.c_int, [C.c_void_p]),
+    "mgx_rccl_connect": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgx_rccl_disconnect": (C.c_int, []),
+    "mgx_rccl_selftest": (C.c_int, []),
+    "mgx_transport": (C.c_char_p, []),
     "mgx_last_error": (C.c_char_p, []),
     "mgx_version": (C.c_char_p, []),
 }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,7 +27,7 @@ struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 
 extern "C" {
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
-int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides);
+int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_has_reg_kernel(const LevView *);
@@ -65,6 +66,17 @@ void mgxm_flux_zero_face(hipStream_t, const GeoView *, double *, int face, int p
 void mgxm_flux_face_copy(hipStream_t, const GeoView *, double *, double *, int face, int pl, int unpack);
 void mgxm_rhs_accum(hipStream_t, const GeoView *, double *, const double *, int);
 void mgxm_correct_uvw(hipStream_t, const GeoView *, const double *, const ModelView *);
+// native RCCL transport (mgx_rccl.cpp)
+const char *mgxr_last_error(void);
+const char *mgxr_library(void);
+int mgxr_connected(void);
+int mgxr_nranks(void);
+int mgxr_get_unique_id(void *);
+int mgxr_connect(const void *, int, int);
+void mgxr_disconnect(void);
+int mgxr_exchange(hipStream_t, int, const int *, double *const *, double *const *, const int *);
+int mgxr_allreduce(hipStream_t, double *, int);
+int mgxr_allgather(hipStream_t, const int *, int, const double *, double *, int);
 }
 
 namespace {
@@ -99,6 +111,7 @@ struct State {
   double hlim = 0, theta_b = 0, theta_s = 0;
   hipStream_t stream = nullptr;
   mgx_exchange_fn ex = nullptr; mgx_allreduce_fn ar = nullptr; mgx_allgather_fn ag = nullptr; void *ctx = nullptr;
+  bool native_rccl = false;  // the hooks are the library's own RCCL transport (mgx_rccl_connect)
   double *d_partial = nullptr; int npartial = 0;
   double *d_scalar = nullptr; double *h_scalar = nullptr;
   double *ref_scratch = nullptr; size_t ref_scratch_n = 0;  // reference-layout staging (8 x level-1 field)
@@ -112,12 +125,16 @@ struct State {
   unsigned int *p2p_counter = nullptr;
   int *p2p_err = nullptr;   // host-mapped
   long long n_p2p = 0;
-  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_rmask = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
+  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
+  // the mask handed to nhydro_solve / nhydro_check_nondivergence on THIS call (nhydro.f90:72,82,98): staging copy in the
+  // caller's layout and the i-fastest copy the model-space kernels read; call_mask = a mask came with the current call
+  double *d_rmask_ref = nullptr, *d_rmask_m = nullptr; bool call_mask = false;
   std::vector<void *> allocs;
   int verbose = 1;
   int warm_start = 0;   // keep p between solves instead of the reference's cold start (mg_solvers.f90:35)
   int tictoc = 0;       // per-(level,name) GPU timers in the shape of mg_tictoc.f90
   int rb_chain = 1;     // red-black: chained k=1 snapshots on closed levels (0 = one snapshot launch per colour pass, for A/B tests)
+  int rb_exact = 0;     // red-black with cmatrix='real' in the reference's SEQUENTIAL order (plane after plane): bit-identical to mg_relax.f90:170-186, slow
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
@@ -213,9 +230,14 @@ void rank_level_table(int rank, std::vector<Level> &T, int npx0, int npy0, int n
 int exchange(int n, const int *peer, double *const *sb, double *const *rb, const int *cnt) {
   if (!S.ex) return fail("a halo exchange is needed (npx*npy > 1) but mgx_set_comm was not called");
   S.n_exch++;
-  if (S.ex(S.ctx, n, peer, sb, rb, cnt)) return fail("exchange callback failed");
+  if (S.ex(S.ctx, n, peer, sb, rb, cnt)) return fail("exchange callback failed%s%s", S.native_rccl ? ": " : "", S.native_rccl ? mgxr_last_error() : "");
   return 0;
 }
+
+// the three hooks of mgx_set_comm served by the library's own RCCL communicator (mgx_rccl_connect), on the solver's stream
+int rccl_exchange_hook(void *, int n, const int *peer, double *const *sb, double *const *rb, const int *cnt) { return mgxr_exchange(S.stream, n, peer, sb, rb, cnt); }
+int rccl_allreduce_hook(void *, double *buf, int n) { return mgxr_allreduce(S.stream, buf, n); }
+int rccl_allgather_hook(void *, const int *group, int ng, const double *sb, double *rb, int cnt) { return mgxr_allgather(S.stream, group, ng, sb, rb, cnt); }
 
 // fill_halo_3D_relax / fill_halo_3D for the JS fields p,b,r (nh = 1): mg_mpi_exchange.f90:396-745
 int fill_halo_js(Level &L, double *a, bool phys_done = false) {
@@ -408,10 +430,23 @@ int relax(int lev, int nsweeps) {
     return 0;
   }
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
-  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph)) { S.n_launch++; return 0; }
+  const int exact = S.method == M_RB && S.real && S.rb_exact;
+  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact)) { S.n_launch++; return 0; }
   const bool closed = ph.S && ph.E && ph.N && ph.W;
   double *const p1a = L.v.p1;
   for (int it = 1; it <= nsweeps; it++) {
+    if (exact) {
+      // The reference's red-black loop is sequential (mg_relax.f90:170-186): with cmatrix='real' a column of plane i reads the
+      // same-colour k=1 diagonals (j+-1,i-1) already updated and (j+-1,i+1) not yet (:271-276).  Columns of one colour inside a
+      // plane are independent, so one launch per plane, in order, reproduces the loop bit for bit -- on one rank and, with the
+      // halo filled after each colour as in the reference, its decomposition-dependent result on several.
+      for (int rb = 1; rb <= 2; rb++) {
+        int fused = 0;
+        for (int i = 1; i <= L.nx; i++) { fused = mgxk_relax_colour(S.stream, &L.v, i, 1, 1, -1, rb, 1, 0, ph); S.n_launch++; }
+        CHK(fill_halo_js(L, L.v.p, fused));
+      }
+      continue;
+    }
     if (S.method == M_RB) {
       // cmatrix='real': the k=1 diagonal neighbours have the column's own colour and must be read as they were before the
       // pass (snapshot).  On a closed level the register kernels write the next sweep's snapshot themselves (two buffers
@@ -563,17 +598,37 @@ int fcycle() {
   return 0;
 }
 
+// Fortran's Ew.3 edit descriptor (0.dddE+ee), so that the printed history reads like the reference's (format 10, mg_solvers.f90:99)
+std::string fortran_e3(double v, int width) {
+  char buf[32];
+  if (v == 0.0 || !std::isfinite(v)) snprintf(buf, sizeof buf, v == 0.0 ? "0.000E+00" : "%f", v);
+  else {
+    const double a = fabs(v);
+    int e = (int)floor(log10(a)) + 1;
+    long m = lround(a / pow(10.0, e) * 1000.0);
+    if (m >= 1000) { m = 100; e++; }
+    if (m < 100) { m *= 10; e--; }
+    if (abs(e) < 100) snprintf(buf, sizeof buf, "%s0.%03ldE%c%02d", v < 0 ? "-" : "", m, e < 0 ? '-' : '+', abs(e));
+    else snprintf(buf, sizeof buf, "%s0.%03ld%c%03d", v < 0 ? "-" : "", m, e < 0 ? '-' : '+', abs(e));
+  }
+  std::string t(buf);
+  if ((int)t.size() < width) t.insert(0, width - t.size(), ' ');
+  return t;
+}
+
 // mg_solvers.f90:17-101
 int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist) {
   Level &L = S.lev[0];
   if (S.verbose && S.rank == 0) printf(" - solve p:\n");
   TicScope ts(1, "solve");  // mg_solvers.f90:45
+  const auto tstart = std::chrono::steady_clock::now();  // cpu_time(tstart) (:46); wall clock here, the work is on the GPU
   if (!S.warm_start) HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));  // grid(1)%p = 0 (:35)
   mgxk_sumsq(S.stream, &L.v, L.v.b, S.d_partial, S.d_scalar); S.n_launch += 2;
   double bnorm; CHK(global_sum(L, &bnorm)); bnorm = sqrt(bnorm);
   int nite = 0;
   double rnorm; CHK(residual(1, &rnorm));
   double res0 = rnorm / bnorm;
+  const double rnorm0 = res0;
   if (hist) hist[0] = res0;
   FILE *f100 = (S.verbose && S.rank == 0) ? fopen("fort.100", "a") : nullptr;
   if (f100) fprintf(f100, " %24.16E %d\n", res0, nite);
@@ -585,10 +640,16 @@ int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist
     res0 = rnorm;
     nite++;
     if (hist) hist[nite] = rnorm;
-    if (S.verbose && S.rank == 0) printf("ite = %2d: res = %10.3E / conv = %10.3f\n", nite, rnorm, conv);
+    if (S.verbose && S.rank == 0) printf("ite = %2d: res = %s / conv = %10.3f\n", nite, fortran_e3(rnorm, 10).c_str(), conv);
     if (f100) fprintf(f100, " %24.16E %24.16E\n", rnorm, conv);
   }
   if (f100) fclose(f100);
+  if (S.verbose && S.rank == 0) {  // the summary block (mg_solvers.f90:83-97)
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
+    const double np = (double)L.npx * L.npy, ncell = (double)L.nx * L.npx * (double)L.ny * L.npy * (double)L.nz;
+    const double perf = dt * np / (-log(res0 / rnorm0) / log(10.0)) / ncell;
+    printf(" --- summary ---\ntime spent to solve :%8.3f s\nrescaled performance:%s\n ---------------\n", dt, fortran_e3(perf, 10).c_str());
+  }
   if (nite_out) *nite_out = nite;
   if (res_out) *res_out = res0;
   return 0;
@@ -665,8 +726,25 @@ int define_matrices() {
   return 0;
 }
 
-// the model fields + the level-1 mask (only read when bmask)
-ModelView model_view() { return ModelView{S.d_u, S.d_v, S.d_w, S.par.bmask ? S.lev[0].g.mrmask : nullptr, S.par.bmask ? 1 : 0}; }
+// the model fields + the mask of the call.  The reference multiplies the w cross terms of compute_rhs by the rmask of the
+// call whatever bmask says, and builds umask / vmask from it only when bmask (mg_compute_rhs.f90:56-72,110-111,
+// mg_correct_uvw.f90:51-68).  Without a per-call mask (NULL): the level-1 mask of nhydro_matrices when bmask, else all ones.
+ModelView model_view() {
+  double *m = S.call_mask ? S.d_rmask_m : (S.par.bmask ? S.lev[0].g.mrmask : nullptr);
+  return ModelView{S.d_u, S.d_v, S.d_w, m, S.par.bmask ? 1 : 0};
+}
+
+// rmaska of nhydro_solve / nhydro_check_nondivergence: (0:ny+1,0:nx+1), j fastest -- the layout the reference's drivers
+// allocate (mg_testseamount.f90:97) and compute_rhs indexes (rmask(j,i)).  `dev`: the pointer is a device pointer.
+int set_call_mask(const double *rmask, bool dev) {
+  S.call_mask = rmask != nullptr;
+  if (!rmask) return 0;
+  Level &L = S.lev[0];
+  const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2) * sizeof(double);
+  HIPCHK(hipMemcpyAsync(S.d_rmask_ref, rmask, n2, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, S.stream));
+  mgxm_ref2model_2d(S.stream, S.d_rmask_ref, S.d_rmask_m, L.nx, L.ny); S.n_launch++;
+  return 0;
+}
 
 // fill_halo(1,uf,lbc_null='u') / fill_halo(1,vf,lbc_null='v') (mg_compute_rhs.f90:171,272), reduced to the entries the
 // divergence reads: the first and last face.  Physical side: zero flux.  Neighbour: my last face is the neighbour's first
@@ -777,7 +855,67 @@ const char *mgx_last_error(void) { return S.err.c_str(); }
 const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 int mgx_set_verbose(int v) { S.verbose = v; return 0; }
 int mgx_set_stream(void *st) { S.stream = (hipStream_t)st; return 0; }
-int mgx_set_comm(mgx_exchange_fn ex, mgx_allreduce_fn ar, mgx_allgather_fn ag, void *ctx) { S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx; return 0; }
+int mgx_set_comm(mgx_exchange_fn ex, mgx_allreduce_fn ar, mgx_allgather_fn ag, void *ctx) { S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx; S.native_rccl = false; return 0; }
+
+// ---- native RCCL transport -------------------------------------------------------------------------------------
+int mgx_rccl_unique_id_bytes(void) { return 128; }
+int mgx_rccl_get_unique_id(void *id_out) { if (mgxr_get_unique_id(id_out)) return fail("mgx_rccl_get_unique_id: %s", mgxr_last_error()); return 0; }
+int mgx_rccl_connect(const void *id, int nranks, int rank) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail("mgx_rccl_connect: rank %d of %d", rank, nranks);
+  if (mgxr_connect(id, nranks, rank)) return fail("mgx_rccl_connect: %s", mgxr_last_error());
+  S.ex = rccl_exchange_hook; S.ar = rccl_allreduce_hook; S.ag = rccl_allgather_hook; S.ctx = nullptr; S.native_rccl = true;
+  return 0;
+}
+int mgx_rccl_disconnect(void) {
+  if (S.native_rccl) { S.ex = nullptr; S.ar = nullptr; S.ag = nullptr; S.native_rccl = false; }
+  mgxr_disconnect();
+  return 0;
+}
+// Collective self-test of the native transport (any world size, after mgx_init): an all-reduce of rank+1 and one grouped
+// exchange of rank-coded buffers with the next and the previous rank (with itself on one rank) through the same hooks the
+// halo fills use.  0 = every value arrived.
+int mgx_rccl_selftest(void) {
+  NEED_INIT();
+  if (!S.native_rccl || !mgxr_connected()) return fail("mgx_rccl_selftest: the native RCCL transport is not connected");
+  const int n = mgxr_nranks(), me = S.rank;
+  if (n != S.nranks) return fail("mgx_rccl_selftest: communicator has %d ranks, the solver %d", n, S.nranks);
+  const int cnt = (int)std::min<size_t>(1000, S.xbuf_n);
+  int peers[2], np = 0;
+  peers[np++] = (me + 1) % n;
+  if ((me - 1 + n) % n != peers[0]) peers[np++] = (me - 1 + n) % n;
+  std::vector<double> h(cnt);
+  double *sb[2], *rb[2]; int cn[2];
+  for (int q = 0; q < np; q++) {
+    for (int t = 0; t < cnt; t++) h[t] = 1000.0 * me + peers[q] + 1e-3 * t;
+    HIPCHK(hipMemcpyAsync(S.xbuf[q], h.data(), cnt * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPCHK(hipStreamSynchronize(S.stream));
+    HIPCHK(hipMemsetAsync(S.xbuf[8 + q], 0, cnt * sizeof(double), S.stream));
+    sb[q] = S.xbuf[q]; rb[q] = S.xbuf[8 + q]; cn[q] = cnt;
+  }
+  CHK(exchange(np, peers, sb, rb, cn));
+  for (int q = 0; q < np; q++) {
+    HIPCHK(hipMemcpyAsync(h.data(), S.xbuf[8 + q], cnt * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    CHK(sync_stream());
+    for (int t = 0; t < cnt; t++) if (h[t] != 1000.0 * peers[q] + me + 1e-3 * t) return fail("mgx_rccl_selftest: wrong data from rank %d (element %d)", peers[q], t);
+  }
+  S.h_scalar[0] = me + 1.0;
+  HIPCHK(hipMemcpyAsync(S.d_scalar, S.h_scalar, sizeof(double), hipMemcpyHostToDevice, S.stream));
+  if (S.ar(S.ctx, S.d_scalar, 1)) return fail("mgx_rccl_selftest: all-reduce failed: %s", mgxr_last_error());
+  HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  CHK(sync_stream());
+  if (S.h_scalar[0] != 0.5 * n * (n + 1)) return fail("mgx_rccl_selftest: all-reduce gave %g, expected %g", S.h_scalar[0], 0.5 * n * (n + 1));
+  return 0;
+}
+// which transport carries the neighbour traffic right now
+const char *mgx_transport(void) {
+  static std::string t;
+  if (S.nranks <= 1 && !S.native_rccl) t = "none (one rank)";
+  else {
+    t = S.native_rccl ? std::string("RCCL, native (") + mgxr_library() + ")" : (S.ex ? "host callbacks (mgx_set_comm)" : "none");
+    if (S.p2p_on) t = "peer-to-peer pushes over hipIpc-shared buffers for the cycle's halos and gathers; " + t + " for set-up halos and the norm";
+  }
+  return t.c_str();
+}
 
 int mgx_params_default(mgx_params *p) {
   memset(p, 0, sizeof(*p));
@@ -836,10 +974,11 @@ void mgx_clean(void) {
   for (void *q : S.allocs) (void)hipFree(q);
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos;
-  mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact;
+  mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.native_rccl = nat;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -937,11 +1076,14 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_w, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   CHK(dmalloc(&S.d_bm, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
+  CHK(dmalloc(&S.d_rmask_ref, (size_t)(L1.nx + 2) * (L1.ny + 2))); CHK(dmalloc(&S.d_rmask_m, (size_t)(L1.nx + 2) * (L1.ny + 2)));
+  S.call_mask = false;
   CHK(sync_stream());
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
   if (getenv("MGX_TICTOC")) S.tictoc = 1;
+  if (getenv("MGX_RB_EXACT")) S.rb_exact = atoi(getenv("MGX_RB_EXACT"));
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
@@ -976,8 +1118,8 @@ int mgx_matrices(const double *dx, const double *dy, const double *zeta, const d
 
 int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask) {
   NEED_INIT();
-  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before compute_rhs");
+  CHK(set_call_mask(rmask, false));
   CHK(upload_uvw(u, v, w));
   CHK(compute_rhs_dev());
   CHK(sync_stream());
@@ -986,9 +1128,9 @@ int mgx_compute_rhs(const double *u, const double *v, const double *w, const dou
 
 int mgx_solve(double *u, double *v, double *w, const double *rmask) {
   NEED_INIT();
-  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve");
   if (S.verbose && S.rank == 0) printf("  nhydro_solve:\n");
+  CHK(set_call_mask(rmask, false));
   CHK(upload_uvw(u, v, w));
   CHK(compute_rhs_dev());
   CHK(solve_p(S.par.solver_prec, S.par.solver_maxiter, nullptr, nullptr, nullptr));
@@ -1006,8 +1148,8 @@ int mgx_solve(double *u, double *v, double *w, const double *rmask) {
 // (e.g. torch tensors); nothing crosses PCIe.  The library's own staging copies are bypassed.
 int mgx_solve_device(double *u_dev, double *v_dev, double *w_dev, const double *rmask) {
   NEED_INIT();
-  (void)rmask;  // the level-1 mask handed to mgx_matrices is the one used (compute_rhs reads grid(1) geometry too)
   if (!S.have_matrix) return fail("mgx_matrices must be called before mgx_solve_device");
+  CHK(set_call_mask(rmask, true));
   double *su = S.d_u, *sv = S.d_v, *sw = S.d_w;
   S.d_u = u_dev; S.d_v = v_dev; S.d_w = w_dev;
   int rc = compute_rhs_dev();
@@ -1066,6 +1208,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "exact_halos")) S.exact_halos = value;
   else if (streq(name, "verbose")) S.verbose = value;
   else if (streq(name, "rb_chain")) S.rb_chain = value;
+  else if (streq(name, "rb_exact")) S.rb_exact = value;
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;

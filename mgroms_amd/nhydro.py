@@ -65,13 +65,8 @@ def nhydro_init(nx, ny, nz, npxg=1, npyg=1, rank=0, params=None, comm=None):
         comm.install()
     check(lib().mgx_init(nx, ny, nz, npxg, npyg, rank, None if params is None else C.byref(params)))
     _state["dims"] = (nx, ny, nz)
-    if comm is not None and comm.p2p and npxg * npyg > 1:
-        try:
-            comm.connect_p2p()
-        except Exception as e:  # the halo pushes are an optimisation: anything unexpected leaves the callback transport in charge
-            comm.p2p_active = False
-            comm.p2p_error = f"connect_p2p raised {e!r}"
-            lib().mgx_set_option(b"p2p", 0)
+    if comm is not None and npxg * npyg > 1:
+        comm.after_init()
 
 
 def nhydro_matrices(dx, dy, zeta, h, rmask=None, hc=0.0, theta_b=0.0, theta_s=0.0):
@@ -90,31 +85,46 @@ def _uvw(u, v, w):
             raise ValueError(f"{n}: need a C-contiguous float64 array of shape {sh} (updated in place)")
 
 
+def _mask(rmask):
+    """rmaska of the call, (0:ny+1,0:nx+1) in Fortran = numpy (nx+2, ny+2); None = the mask of nhydro_matrices / all ones."""
+    if rmask is None:
+        return None, None
+    nx, ny, _ = _state["dims"]
+    rm = _f64(rmask, (nx + 2, ny + 2), "rmask")
+    return rm, _dp(rm)
+
+
 def nhydro_solve(u, v, w, rmask=None):
     """nhydro_solve (nhydro.f90:53): u(1:nx+1,0:ny+1,1:nz) = numpy (nz, ny+2, nx+1) etc.; corrected in place."""
     _uvw(u, v, w)
-    check(lib().mgx_solve(_dp(u), _dp(v), _dp(w), None))
+    rm, prm = _mask(rmask)
+    check(lib().mgx_solve(_dp(u), _dp(v), _dp(w), prm))
 
 
-def nhydro_solve_device(u, v, w):
-    """nhydro_solve on torch CUDA tensors (float64, contiguous, shapes as nhydro_solve): no host round trip."""
+def nhydro_solve_device(u, v, w, rmask=None):
+    """nhydro_solve on torch CUDA tensors (float64, contiguous, shapes as nhydro_solve; rmask (nx+2, ny+2)): no host round trip."""
     nx, ny, nz = _state["dims"]
     for a, sh, n in ((u, (nz, ny + 2, nx + 1), "u"), (v, (nz, ny + 1, nx + 2), "v"), (w, (nz + 1, ny + 2, nx + 2), "w")):
         if not (a.is_cuda and a.is_contiguous() and tuple(a.shape) == sh and str(a.dtype) == "torch.float64"):
             raise ValueError(f"{n}: need a contiguous float64 CUDA tensor of shape {sh}")
     import torch
     torch.cuda.current_stream().synchronize()
-    check(lib().mgx_solve_device(C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(w.data_ptr()), None))
+    if rmask is not None and not (rmask.is_cuda and rmask.is_contiguous() and tuple(rmask.shape) == (nx + 2, ny + 2) and str(rmask.dtype) == "torch.float64"):
+        raise ValueError(f"rmask: need a contiguous float64 CUDA tensor of shape {(nx + 2, ny + 2)}")
+    check(lib().mgx_solve_device(C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(w.data_ptr()),
+                                 None if rmask is None else C.c_void_p(rmask.data_ptr())))
 
 
 def nhydro_check_nondivergence(u, v, w, rmask=None):
     _uvw(u, v, w)
-    check(lib().mgx_check_nondivergence(_dp(u), _dp(v), _dp(w), None))
+    rm, prm = _mask(rmask)
+    check(lib().mgx_check_nondivergence(_dp(u), _dp(v), _dp(w), prm))
 
 
 def compute_rhs(u, v, w, rmask=None):
     _uvw(u, v, w)
-    check(lib().mgx_compute_rhs(_dp(u), _dp(v), _dp(w), None))
+    rm, prm = _mask(rmask)
+    check(lib().mgx_compute_rhs(_dp(u), _dp(v), _dp(w), prm))
 
 
 def nhydro_clean():

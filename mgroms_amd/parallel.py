@@ -34,7 +34,7 @@ class _DevPtr:
 
 
 class Comm:
-    def __init__(self, device="cuda", group=None, p2p=None):
+    def __init__(self, device="cuda", group=None, p2p=None, native=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.device = device
@@ -46,6 +46,11 @@ class Comm:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.staged = self.backend != "nccl"  # gloo moves host memory only
+        # native: libmgx.so's own RCCL communicator serves the three hooks (no Python in the loop); torch.distributed only
+        # carries the 128-byte bootstrap id.  Needs one GPU per rank, i.e. the real multi-GPU case (backend nccl).
+        self.native = (device == "cuda" and not self.staged) if native is None else bool(native)
+        self.native_active = False
+        self.native_error = None
         self._cache = {}
         self._ops = {}
         self.n_exchange = self.n_allreduce = self.n_allgather = 0
@@ -148,9 +153,75 @@ class Comm:
         """Hand the callbacks to libmgx.so and make it launch on torch's current stream, so that kernels,
         packs/unpacks and the RCCL transfers are ordered on one stream."""
         from ._lib import check, lib
-        check(lib().mgx_set_comm(self._ex, self._ar, self._ag, None))
         if self.device == "cuda":
             check(lib().mgx_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if self.native and (self.native_active or self._connect_native()):
+            return
+        check(lib().mgx_set_comm(self._ex, self._ar, self._ag, None))
+
+    def _agree(self, flag):
+        """all ranks together: True only if `flag` is true on every rank"""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if self.staged else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
+
+    def after_init(self):
+        """Collective, right after mgx_init on every rank: self-test of the native RCCL transport (a failure puts every
+        rank back on the callbacks), then the peer-to-peer halo pushes when asked for.  Every decision is taken by all
+        ranks together: a rank that failed alone would otherwise leave its neighbours pushing to flags nobody raises."""
+        from ._lib import check, lib
+        L = lib()
+        if self.native_active:
+            ok = L.mgx_rccl_selftest() == 0
+            if not self._agree(ok):
+                self.native_error = (L.mgx_last_error().decode() if not ok else "self-test failed on another rank")
+                L.mgx_rccl_disconnect()
+                self.native_active = False
+                check(L.mgx_set_comm(self._ex, self._ar, self._ag, None))
+        if not self.p2p:
+            return
+        ok = True
+        try:
+            self.connect_p2p()
+        except Exception as e:  # the halo pushes are an optimisation: anything unexpected leaves the other transport in charge
+            ok = False
+            self.p2p_error = f"connect_p2p raised {e!r}"
+        # the outcome of connect_p2p is already collective when it returns; an exception on one rank is not: agree on it
+        if not self._agree(ok):
+            self.p2p_active = False
+            if self.p2p_error is None:
+                self.p2p_error = "connect_p2p failed on another rank"
+            L.mgx_set_option(b"p2p", 0)
+
+    def _connect_native(self):
+        """Collective: rank 0 creates the RCCL unique id, torch.distributed broadcasts its 128 bytes, every rank joins
+        libmgx.so's communicator.  All-or-nothing: if any rank fails, every rank falls back to the callbacks."""
+        from ._lib import lib
+        L = lib()
+        dev = "cpu" if self.staged else "cuda"
+        nb = L.mgx_rccl_unique_id_bytes()
+        blob = C.create_string_buffer(nb)
+        rc = L.mgx_rccl_get_unique_id(blob) if self.rank == 0 else 0
+        t = torch.frombuffer(bytearray(blob.raw), dtype=torch.uint8).clone().to(dev)
+        src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+        dist.broadcast(t, src=src, group=self.group)
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 1:
+            rc = L.mgx_rccl_connect(bytes(t.cpu().numpy().tobytes()), self.world, self.rank)
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) != 1:
+            self.native_error = L.mgx_last_error().decode() or "a peer could not join the RCCL communicator"
+            L.mgx_rccl_disconnect()
+            self.native_active = False
+            return False
+        self.native_active = True
+        return True
+
+    def transport(self):
+        from ._lib import lib
+        return lib().mgx_transport().decode()
 
 
     def connect_p2p(self):

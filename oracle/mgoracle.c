@@ -73,12 +73,14 @@ typedef struct {
   olev *lev;      /* [nlevs], index 0 = level 1 */
   double *u, *v, *w; /* model arrays (i,j,k): u(1:nx+1,0:ny+1,1:nz) v(0:nx+1,1:ny+1,1:nz) w(0:nx+1,0:ny+1,0:nz) */
   double *dum_nz, *dum_nzp; /* dummy3Dnz / dummy3Dnzp, level 1 */
+  double *rmaska;           /* the mask handed to nhydro_solve / nhydro_check_nondivergence (nhydro.f90:56,72), (0:ny+1,0:nx+1) */
 } orank;
 
 typedef struct {
   mgo_params par;
   int nlevs, npx, npy, nranks;
   double hlim, theta_b, theta_s;
+  int use_rmaska; /* 1: compute_rhs / correct_uvw read the per-call mask rmaska; 0: the caller passed the mask of nhydro_matrices */
   orank *rk;
 } oworld;
 
@@ -969,7 +971,7 @@ static void compute_rhs(oworld *W, const double *const *rmask_by_rank) {
       orank *R = &W->rk[r];
       olev *L = &R->lev[0];
       int nx = L->nx, ny = L->ny, nz = L->nz;
-      const double *rm = L->rmask; /* the reference indexes the model's rmask as (j,i), mg_compute_rhs.f90:61,110 */
+      const double *rm = W->use_rmaska ? R->rmaska : L->rmask; /* the reference indexes the model's rmask as (j,i), mg_compute_rhs.f90:61,110 */
 #define RM(j, i) rm[I2(L, j, i)]
       /* umask(j,i)=rmask(j,i-1)*rmask(j,i) for i>=1, vmask(j,i)=rmask(j-1,i)*rmask(j,i) for j>=1, else 0 (:56-72) */
 #define UMK(j, i) (bmask ? (((i) >= 1) ? RM(j, (i)-1) * RM(j, i) : 0.0) : 1.0)
@@ -1127,16 +1129,17 @@ static void correct_uvw(oworld *W) {
     orank *R = &W->rk[r];
     olev *L = &R->lev[0];
     int nx = L->nx, ny = L->ny, nz = L->nz;
+    const double *rm = W->use_rmaska ? R->rmaska : L->rmask; /* umask, vmask from the rmask of the call (mg_correct_uvw.f90:51-68) */
 #define Wv(i, j, k) R->w[(((size_t)(k)) * (ny + 2) + (j)) * (nx + 2) + (i)]
 #define V(i, j, k) R->v[(((size_t)((k)-1)) * (ny + 1) + ((j)-1)) * (nx + 2) + (i)]
 #define P(k, j, i) L->p[I3(L, k, j, i)]
     for (int i = 1; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
       double dxu = hlf * (L->dx[I2(L, j, i)] + L->dx[I2(L, j, i - 1)]);
-      U(i, j, k) = U(i, j, k) - one / dxu * (P(k, j, i) - P(k, j, i - 1)) * (bmask ? L->rmask[I2(L, j, i - 1)] * L->rmask[I2(L, j, i)] : 1.0);
+      U(i, j, k) = U(i, j, k) - one / dxu * (P(k, j, i) - P(k, j, i - 1)) * (bmask ? rm[I2(L, j, i - 1)] * rm[I2(L, j, i)] : 1.0);
     }
     for (int i = 0; i <= nx + 1; i++) for (int j = 1; j <= ny + 1; j++) for (int k = 1; k <= nz; k++) {
       double dyv = hlf * (L->dy[I2(L, j, i)] + L->dy[I2(L, j - 1, i)]);
-      V(i, j, k) = V(i, j, k) - one / dyv * (P(k, j, i) - P(k, j - 1, i)) * (bmask ? L->rmask[I2(L, j - 1, i)] * L->rmask[I2(L, j, i)] : 1.0);
+      V(i, j, k) = V(i, j, k) - one / dyv * (P(k, j, i) - P(k, j - 1, i)) * (bmask ? rm[I2(L, j - 1, i)] * rm[I2(L, j, i)] : 1.0);
     }
     for (int i = 0; i <= nx + 1; i++) for (int j = 0; j <= ny + 1; j++) {
       for (int k = 2; k <= nz; k++) {
@@ -1186,6 +1189,8 @@ void *mgo_create(int nxl, int nyl, int nzl, int npx, int npy, const mgo_params *
     R->w = dalloc((size_t)(L->nx + 2) * (L->ny + 2) * (L->nz + 1));
     R->dum_nz = dalloc((size_t)(L->ny + 2) * (L->nx + 2) * L->nz);
     R->dum_nzp = dalloc((size_t)(L->ny + 2) * (L->nx + 2) * (L->nz + 1));
+    R->rmaska = dalloc((size_t)(L->ny + 2) * (L->nx + 2));
+    for (size_t q = 0; q < (size_t)(L->ny + 2) * (L->nx + 2); q++) R->rmaska[q] = 1.0;
   }
   return W;
 }
@@ -1200,7 +1205,7 @@ void mgo_destroy(void *h) {
       free(L->zr); free(L->zw); free(L->cw); free(L->dzw); free(L->zxdy); free(L->zydx);
       if (l > 0) { free(L->dummy3); for (int q = 0; q < 4; q++) free(L->tmp2[q]); }
     }
-    free(R->lev); free(R->u); free(R->v); free(R->w); free(R->dum_nz); free(R->dum_nzp);
+    free(R->lev); free(R->u); free(R->v); free(R->w); free(R->dum_nz); free(R->dum_nzp); free(R->rmaska);
   }
   free(W->rk); free(W);
 }
@@ -1215,7 +1220,7 @@ void mgo_level_info(void *h, int rank, int lev, int *out) {
   memcpy(out + 12, L->neighb, sizeof(int) * 8);
 }
 
-/* field ids: 0 p,1 b,2 r,3 cA,4 dx,5 dy,6 zeta,7 h,8 zr,9 zw,10 cw,11 u,12 v,13 w,14 rmask */
+/* field ids: 0 p,1 b,2 r,3 cA,4 dx,5 dy,6 zeta,7 h,8 zr,9 zw,10 cw,11 u,12 v,13 w,14 rmask,15 rmaska (per-call mask) */
 double *mgo_field(void *h, int rank, int lev, int id) {
   orank *R = &((oworld *)h)->rk[rank];
   olev *L = &R->lev[lev - 1];
@@ -1223,7 +1228,7 @@ double *mgo_field(void *h, int rank, int lev, int id) {
     case 0: return L->p; case 1: return L->b; case 2: return L->r; case 3: return L->cA;
     case 4: return L->dx; case 5: return L->dy; case 6: return L->zeta; case 7: return L->h;
     case 8: return L->zr; case 9: return L->zw; case 10: return L->cw;
-    case 11: return R->u; case 12: return R->v; case 13: return R->w; case 14: return L->rmask;
+    case 11: return R->u; case 12: return R->v; case 13: return R->w; case 14: return L->rmask; case 15: return R->rmaska;
   }
   return NULL;
 }
@@ -1235,6 +1240,8 @@ void mgo_matrices(void *h, double hc, double theta_b, double theta_s) {
   define_matrices(W);
 }
 
+/* 1: the next compute_rhs / correct_uvw use the per-call mask (field 15) like nhydro_solve(…,rmaska,…) does */
+void mgo_use_call_mask(void *h, int on) { ((oworld *)h)->use_rmaska = on; }
 void mgo_compute_rhs(void *h) { compute_rhs((oworld *)h, NULL); }
 void mgo_correct_uvw(void *h) { correct_uvw((oworld *)h); }
 int mgo_solve_p(void *h, double tol, int maxite, double *hist, double *bnorm) { return solve_p((oworld *)h, tol, maxite, hist, bnorm); }

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libmgoracle.so")
 
 FIELD = {"p": 0, "b": 1, "r": 2, "cA": 3, "dx": 4, "dy": 5, "zeta": 6, "h": 7,
-         "zr": 8, "zw": 9, "cw": 10, "u": 11, "v": 12, "w": 13, "rmask": 14}
+         "zr": 8, "zw": 9, "cw": 10, "u": 11, "v": 12, "w": 13, "rmask": 14, "rmaska": 15}
 METHOD = {"GS": 0, "Gauss-Seidel": 0, "RB": 1, "Red-Black": 1, "FC": 2, "Four-Color": 2}
 
 
@@ -65,6 +65,7 @@ def lib():
         L.mgo_fine2coarse.argtypes = [C.c_void_p, C.c_int]
         L.mgo_coarse2fine.argtypes = [C.c_void_p, C.c_int]
         L.mgo_fill_halo.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mgo_use_call_mask.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -109,7 +110,7 @@ class Oracle:
         shape = {"p": (nx + 2, ny + 2, nz), "b": (nx + 2, ny + 2, nz), "r": (nx + 2, ny + 2, nz),
                  "cA": (nx + 2, ny + 2, nz, 8), "dx": (nx + 2, ny + 2), "dy": (nx + 2, ny + 2),
                  "zeta": (nx + 2, ny + 2), "h": (nx + 2, ny + 2), "rmask": (nx + 2, ny + 2), "zr": (nx + 4, ny + 4, nz),
-                 "zw": (nx + 4, ny + 4, nz + 1), "cw": (nx + 2, ny + 2, nz + 1),
+                 "zw": (nx + 4, ny + 4, nz + 1), "cw": (nx + 2, ny + 2, nz + 1), "rmaska": (l1["nx"] + 2, l1["ny"] + 2),
                  "u": (l1["nz"], l1["ny"] + 2, l1["nx"] + 1), "v": (l1["nz"], l1["ny"] + 1, l1["nx"] + 2),
                  "w": (l1["nz"] + 1, l1["ny"] + 2, l1["nx"] + 2)}[name]
         ptr = lib().mgo_field(self.h, rank, lev, FIELD[name])
@@ -124,6 +125,11 @@ class Oracle:
 
     def correct_uvw(self):
         lib().mgo_correct_uvw(self.h)
+
+    def use_call_mask(self, on=True):
+        """compute_rhs / correct_uvw read field "rmaska" (the mask handed to nhydro_solve, nhydro.f90:56,72) instead of
+        the level-1 mask of nhydro_matrices."""
+        lib().mgo_use_call_mask(self.h, 1 if on else 0)
 
     def solve_p(self, tol=None, maxite=None):
         tol = self.par.solver_prec if tol is None else tol

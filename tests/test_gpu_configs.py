@@ -1,0 +1,263 @@
+"""BASELINE.json configurations at their own sizes, through the C ABI on the GPU, against the CPU oracle (and the reference's
+printed digits, tests/golden): config 2 (seamount 256x256x32, red-black), config 3 (512x512x64, four-colour, one V-cycle bit
+for bit), config 4 (rndtopo 1024x1024x64 on one GPU against 4x4 emulated ranks; the 2x2 GPU decomposition of the same
+generator is in test_gpu_multirank.py), and the exact-order red-black mode that makes the reference default
+(relax_method='RB', cmatrix='real') a bit-for-bit case.
+
+Tolerances: FC, and RB with rb_exact=1: fields compared with np.array_equal; residual histories |d| <= 1e-13 + 1e-10*ref in
+units of ||b|| (norms are reduced in a different order).  Parallel (default) RB: 5e-5 relative on the history -- the sweep
+reads the same-colour k=1 diagonals as they were before the pass, the reference's sequential loop sees half of them updated
+(the reference differs from ITSELF by 2.5e-6 between 1 and 2x2 ranks for the same reason)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import torch
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    import mgroms_amd as m
+    m.nhydro.set_verbose(0)
+    yield m
+    m.nhydro.set_option("rb_exact", 0)
+    m.nhydro_clean()
+
+
+def _gpu(mg, nx, ny, nz, geom="seamount", **par):
+    from mgroms_amd.testcases import seamount_geometry, rndtopo_geometry, resting_column_state
+    mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(**par))
+    dx, dy, zeta, h = (seamount_geometry if geom == "seamount" else rndtopo_geometry)(nx, ny)
+    mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+    u, v, w = resting_column_state(nx, ny, nz)
+    mg.nhydro.compute_rhs(u, v, w)
+
+
+def _oracle(nx, ny, nz, npx=1, npy=1, geom="seamount", threads=None, **par):
+    """the same problem on npx x npy emulated ranks (one OpenMP thread each)"""
+    from oracle.mgoracle import Oracle, seamount_geometry, rndtopo_geometry
+    o = Oracle(nx // npx, ny // npy, nz, npx, npy, **par)
+    g = seamount_geometry if geom == "seamount" else rndtopo_geometry
+    for r in range(npx * npy):
+        for name, a in zip(("dx", "dy", "zeta", "h"), g(nx // npx, ny // npy, npx, npy, r)):
+            o.field(name, 1, r)[...] = a
+    o.matrices(4e3, 0.0, 0.0)
+    for r in range(npx * npy):
+        o.field("u", 1, r)[...] = 0.0
+        o.field("v", 1, r)[...] = 0.0
+        w = o.field("w", 1, r)
+        w[0] = 0.0
+        w[1:] = -1.0
+    o.compute_rhs()
+    return o
+
+
+def _blocks_equal(p, o, name, npx, npy):
+    """the one-rank GPU field against the oracle's per-rank blocks (interiors)"""
+    lx, ly = (p.shape[0] - 2) // npx, (p.shape[1] - 2) // npy
+    bad = []
+    for r in range(npx * npy):
+        pi, pj = r % npx, r // npx
+        blk = o.field(name, 1, r)[1:-1, 1:-1, :]
+        mine = p[1 + pi * lx:1 + (pi + 1) * lx, 1 + pj * ly:1 + (pj + 1) * ly, :]
+        if not np.array_equal(blk, mine):
+            bad.append((r, float(np.abs(blk - mine).max())))
+    return bad
+
+
+def _hist_close(h, ho):
+    return np.all(np.abs(h - ho) <= 1e-13 + 1e-10 * np.abs(ho))
+
+
+# ---- exact-order red-black -----------------------------------------------------------------------------------------
+def test_rb_exact_matches_reference_history_and_oracle(mg, golden):
+    """relax_method='RB', cmatrix='real' (the reference default) in the reference's sequential order: the 15 residuals of
+    BASELINE.md 3.1 (1 rank) within 1e-13 + 1e-10*ref, p bit for bit against the oracle."""
+    g = golden["seamount_64x64x16_RB_1rank"]
+    mg.nhydro.set_option("rb_exact", 1)
+    try:
+        _gpu(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
+        n, hist = mg.solve_p(1e-6, 50)
+    finally:
+        mg.nhydro.set_option("rb_exact", 0)
+    ref = np.array(g["res"])
+    assert n == g["nite"] == len(ref)
+    assert _hist_close(hist[1:], ref), (hist[1:], ref)
+    o = _oracle(64, 64, 16, relax_method="RB", solver_prec=1e-6)
+    no, ho, _ = o.solve_p(1e-6, 50)
+    assert no == n and _hist_close(hist, ho)
+    p = mg.grid(1).p
+    assert np.array_equal(p, o.field("p"))
+    assert np.isclose((p[1:-1, 1:-1, :] ** 2).sum(), g["sum_p2"], rtol=1e-12)
+    # the default (parallel) sweep on the same problem differs, within the stated tolerance
+    _gpu(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
+    n2, hist2 = mg.solve_p(1e-6, 50)
+    assert n2 == n and not np.array_equal(hist2, hist) and np.all(np.abs(hist2[1:] - ref) <= 5e-5 * ref)
+
+
+@pytest.mark.parametrize("dims", [(32, 16, 8), (16, 64, 4), (128, 32, 8)])
+def test_rb_exact_relax_every_level(mg, dims):
+    """one relax call per level (per-plane launches on the large levels, the one-workgroup kernels on the small ones) from a
+    random state: bit-identical to the oracle's sequential loop; ragged blocks included"""
+    nx, ny, nz = dims
+    mg.nhydro.set_option("rb_exact", 1)
+    try:
+        _gpu(mg, nx, ny, nz, relax_method="RB")
+        o = _oracle(nx, ny, nz, relax_method="RB")
+        rng = np.random.default_rng(5)
+        for lev in range(1, o.nlevs + 1):
+            g = mg.grid(lev)
+            p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+            g.set("p", p); g.set("b", b); mg.fill_halo(lev, "p")
+            o.field("p", lev)[...] = p; o.field("b", lev)[...] = b; o.fill_halo(lev, "p")
+            mg.relax(lev, 2); o.relax(lev, 2)
+            assert np.array_equal(g.get("p"), o.field("p", lev)), lev
+    finally:
+        mg.nhydro.set_option("rb_exact", 0)
+
+
+def test_relax_rb_parallel_deviation_is_small(mg):
+    """What the parallel red-black sweep (default) actually differs by from the sequential one after ONE sweep on a smooth
+    field (the solve's own iterate): the k=1 diagonal coupling times the change of one sweep."""
+    _gpu(mg, 64, 64, 16, relax_method="RB")
+    mg.Vcycle(1)
+    p0, b0 = mg.grid(1).p, mg.grid(1).b
+    o = _oracle(64, 64, 16, relax_method="RB")
+    o.field("p")[...] = p0
+    o.field("b")[...] = b0
+    mg.relax(1, 1); o.relax(1, 1)
+    a, c = mg.grid(1).p, o.field("p")
+    d = np.abs(a - c).max() / np.abs(c).max()
+    assert 0 < d <= 1e-4, d
+
+
+# ---- BASELINE config 2: seamount 256x256x32, red-black ---------------------------------------------------------------
+def test_config2_rb_256x256x32(mg, golden):
+    ref = golden["seamount_256x256x32_RB_printed"]
+    # (a) the default (parallel) sweep, 50 iterations as the reference runs it (it stops at maxiter)
+    _gpu(mg, 256, 256, 32, relax_method="RB", solver_prec=1e-8)
+    n, hist = mg.solve_p(1e-8, 50)
+    assert n == 50 == ref["nite"]
+    assert np.all(np.abs(hist[1:6] - np.array(ref["first5"])) <= 6e-4), hist[1:6]       # printed with 3 digits
+    assert abs(hist[50] - ref["res50"]) <= 0.0006e-5 + 5e-5 * ref["res50"], hist[50]    # 0.426E-05
+    hist_par = hist.copy()
+    # (b) exact order: first 3 iterations bit for bit against the oracle on one rank; the parallel sweep within 5e-5 of it
+    o = _oracle(256, 256, 32, relax_method="RB")
+    no, ho, _ = o.solve_p(1e-12, 3)
+    mg.nhydro.set_option("rb_exact", 1)
+    try:
+        _gpu(mg, 256, 256, 32, relax_method="RB")
+        n, hist = mg.solve_p(1e-12, 3)
+    finally:
+        mg.nhydro.set_option("rb_exact", 0)
+    assert n == no == 3 and _hist_close(hist, ho)
+    assert np.array_equal(mg.grid(1).p, o.field("p"))
+    assert np.all(np.abs(hist_par[1:4] - ho[1:]) <= 5e-5 * ho[1:])
+    assert np.all(np.abs(ho[1:4] - np.array(ref["first5"][:3])) <= 6e-4)
+
+
+def test_config2_fc_256x256x32_bitwise(mg):
+    _gpu(mg, 256, 256, 32, relax_method="FC")
+    n, hist = mg.solve_p(1e-12, 3)
+    o = _oracle(256, 256, 32, 4, 2, relax_method="FC")
+    no, ho, _ = o.solve_p(1e-12, 3)
+    assert n == no == 3 and _hist_close(hist, ho)
+    assert _blocks_equal(mg.grid(1).p, o, "p", 4, 2) == []
+
+
+# ---- BASELINE config 3: seamount 512x512x64, four-colour, one V-cycle bit for bit ---------------------------------------
+def test_config3_vcycle_512x512x64_bitwise(mg, golden):
+    _gpu(mg, 512, 512, 64, relax_method="FC")
+    b_gpu = mg.grid(1).b
+    mg.Vcycle(1)
+    res = mg.compute_residual(1)
+    o = _oracle(512, 512, 64, 4, 4, relax_method="FC")
+    assert _blocks_equal(b_gpu, o, "b", 4, 4) == []
+    o.vcycle(1)
+    reso = o.residual(1)
+    assert _blocks_equal(mg.grid(1).p, o, "p", 4, 4) == []
+    assert _blocks_equal(mg.grid(1).r, o, "r", 4, 4) == []
+    assert abs(res - reso) <= 1e-12 * reso
+    o.close()
+
+
+# ---- BASELINE config 4: rndtopo 1024x1024x64 -----------------------------------------------------------------------------
+def test_config4_rndtopo_1024x1024x64_bitwise(mg):
+    """mg_testrndtopo's geometry (h = 0.2*Htot*U per cell, mg_setup_tests.f90:199; seeded generator of this build) at the
+    configuration's full size on one GPU against the oracle on 4x4 emulated ranks, two solve_p iterations.  The F-cycle
+    DIVERGES on this input (10 m cells, depth jumps of hundreds of metres) in the oracle and on the GPU alike: a parity
+    and throughput case, not a convergence case."""
+    _gpu(mg, 1024, 1024, 64, geom="rndtopo", relax_method="FC")
+    n, hist = mg.solve_p(1e-12, 2)
+    p = mg.grid(1).p
+    mg.nhydro_clean()
+    o = _oracle(1024, 1024, 64, 4, 4, geom="rndtopo", relax_method="FC")
+    no, ho, _ = o.solve_p(1e-12, 2)
+    assert n == no == 2 and _hist_close(hist, ho), (hist, ho)
+    assert _blocks_equal(p, o, "p", 4, 4) == []
+    o.close()
+
+
+# ---- the mask of the call (nhydro.f90:56,72): honoured with bmask off too ------------------------------------------------
+@pytest.mark.parametrize("bmask", [0, 1])
+def test_call_mask_is_used(mg, bmask):
+    """compute_rhs multiplies the w cross terms by the rmask handed to nhydro_solve whatever bmask says, and builds umask /
+    vmask from it when bmask (mg_compute_rhs.f90:56-72,110-111): a mask that differs from the one of nhydro_matrices must
+    show up in b, u, v, w exactly as in the oracle."""
+    from oracle.mgoracle import Oracle, seamount_geometry
+    from mgroms_amd.testcases import island_mask
+    nx, ny, nz = 32, 32, 8
+    kw = dict(relax_method="FC", solver_prec=1e-9, solver_maxiter=4)
+    mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(bmask=bmask, **kw))
+    dx, dy, zeta, h = seamount_geometry(nx, ny, 1, 1, 0)
+    m0 = island_mask(nx, ny)
+    mg.nhydro_matrices(dx, dy, zeta, h, m0 if bmask else None, 4e3, 0.0, 0.0)
+    o = Oracle(nx, ny, nz, 1, 1, bmask=bool(bmask), **kw)
+    for name, a in (("dx", dx), ("dy", dy), ("zeta", zeta), ("h", h)):
+        o.field(name)[...] = a
+    if bmask:
+        o.field("rmask")[...] = m0
+    o.matrices(4e3, 0.0, 0.0)
+    rng = np.random.default_rng(3)
+    mcall = m0.copy()
+    mcall[5:9, 20:26] = 0.0  # an extra piece of land the matrices have not seen
+    u = rng.uniform(-1, 1, (nz, ny + 2, nx + 1)); v = rng.uniform(-1, 1, (nz, ny + 1, nx + 2)); w = rng.uniform(-1, 1, (nz + 1, ny + 2, nx + 2))
+    o.field("u")[...] = u; o.field("v")[...] = v; o.field("w")[...] = w
+    o.field("rmaska")[...] = mcall
+    o.use_call_mask(True)
+    mg.nhydro.compute_rhs(u, v, w, mcall)
+    o.compute_rhs()
+    b = mg.grid(1).b
+    assert np.array_equal(b, o.field("b"))
+    mg.nhydro.compute_rhs(u, v, w, None)  # without a per-call mask the result is a different one
+    assert not np.array_equal(mg.grid(1).b, b)
+    mg.nhydro_solve(u, v, w, mcall)
+    o.nhydro_solve()
+    assert np.array_equal(mg.grid(1).p, o.field("p"))
+    assert np.array_equal(u, o.field("u")) and np.array_equal(v, o.field("v")) and np.array_equal(w, o.field("w"))
+
+
+def test_native_rccl_world_size_one(mg):
+    """libmgx.so's own RCCL communicator (include/mgx.h: mgx_rccl_*) on a world of one rank: bootstrap, the rank-coded
+    exchange and the all-reduce of mgx_rccl_selftest -- the same hooks a multi-GPU halo fill uses.  (RCCL refuses several
+    ranks on one device, so this is what a one-GPU box can run.)"""
+    import ctypes as C
+    from mgroms_amd._lib import lib, check
+    L = lib()
+    mg.nhydro_clean()
+    blob = C.create_string_buffer(L.mgx_rccl_unique_id_bytes())
+    check(L.mgx_rccl_get_unique_id(blob))
+    check(L.mgx_rccl_connect(blob, 1, 0))
+    try:
+        _gpu(mg, 32, 32, 8, relax_method="FC")
+        assert b"RCCL, native" in L.mgx_transport()
+        check(L.mgx_rccl_selftest())
+        n, hist = mg.solve_p(1e-8, 20)
+        assert hist[-1] <= 1e-8
+    finally:
+        L.mgx_rccl_disconnect()
+        mg.nhydro_clean()

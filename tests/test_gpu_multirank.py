@@ -33,10 +33,14 @@ def _free_port():
     (2, 1, 64, 128, 64, 8, "FC"),   # nz=64: the level-1 kernels of the bench (matrix-free, 3-deep pipeline) with an open side
     (2, 2, 32, 32, 16, 8, "FC+nop2p"), # the exchange callback (torch.distributed) instead of the peer-to-peer pushes
     (2, 2, 16, 16, 8, 8, "FC+bmask"),  # bmask=.true.: masked coefficients + the 4-D cA halo exchange of define_matrix
+    (2, 2, 32, 32, 16, 8, "FC+rndtopo"),  # BASELINE config 4's generator (mg_testrndtopo) on the 2x2 decomposition
+    (2, 2, 32, 64, 128, 16, "FC"),  # BASELINE config 5's shape: nz=128 (k_relax_tall with open sides) + gather at level 3 (nsmall=16)
+    (2, 2, 32, 32, 16, 8, "RB+exact+golden"),  # reference default in the reference's order: its recorded 2x2 history to 1e-10, p bitwise
+    (2, 1, 32, 32, 16, 8, "RB+exact"),  # exact-order red-black with one open side and a 2x1 gather
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     world, port = npx * npy, _free_port()
-    method, _, opt = method.partition("+")
+    method, _, opt = method.partition("+")  # opt: '+'-separated options of tests/_gpu_rank_worker.py
     args = [str(a) for a in (world, npx, npy, port, nx, ny, nz, nsmall)] + [method] + ([opt] if opt else [])
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(r)] + args,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -52,6 +56,21 @@ def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\n{out[-3000:]}"
         assert f"rank {r} ok" in out
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no launcher): bench.py starts its own ranks before touching the GPU.
+    Rehearsed here with both ranks on the one GPU of the box (--backend gloo: host-staged callbacks + hipIpc pushes)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64", "64", "16",
+                          "--steps", "3", "--warmup", "1", "--sweep-reps", "2", "--nsmall", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["halo_transport"]
+    assert "identical" in (j["config"]["transport_check"] or "")
 
 
 def test_multirank_long_edge_path(monkeypatch):
@@ -97,9 +116,27 @@ def test_fortran_mpi_harness(tmp_path, transport):
     o = make_seamount(64, 64, 16, relax_method="FC", solver_prec=1e-10)
     n, h, _ = o.nhydro_solve()
     for (k, r) in its:
-        assert abs(float(r) - h[int(k)]) <= 6e-4 * h[int(k)]  # E10.3 print
+        assert abs(float(r) - h[int(k)]) <= 5.1e-3 * h[int(k)]  # Fortran E10.3: 0.dddE+ee, three significant digits
     sp2 = float(re.search(r"sum_p2 = *([0-9.E+-]+)", stdout).group(1))
     assert np.isclose(sp2, (o.field("p")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-13)
     o.check_nondivergence()
     sd2 = float(re.search(r"sum_div2 = *([0-9.E+-]+)", stdout).group(1))
     assert np.isclose(sd2, (o.field("b")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-9)
+
+
+def test_fortran_mpi_harness_native_rccl(tmp_path):
+    """The Fortran + MPI driver with libmgx.so's native RCCL transport instead of the MPI hooks (MPI only broadcasts the
+    128-byte id): one rank, because RCCL wants one GPU per rank and the box has one."""
+    import re
+    import shutil
+    exe = os.path.join(os.path.dirname(HERE), "fortran", "testseamount_gpu_mpi")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("flang or MPI not available when build() ran")
+    (tmp_path / "nh_namelist").write_text("&nhparam\n relax_method = 'FC',\n solver_prec = 1.d-10,\n/\n")
+    out = subprocess.run([mpiexec, "-n", "1", exe, "1", "1", "64", "64", "16", "rccl"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=120, env=dict(os.environ, OMP_NUM_THREADS="1"), stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rccl_connected =  1" in out.stdout and "rccl_selftest_ok =  1" in out.stdout, out.stdout[-2000:]
+    assert len(re.findall(r"ite = *(\d+): res = *([0-9.E+-]+) / conv", out.stdout)) == 25
+    assert "time spent to solve" in out.stdout and "rescaled performance" in out.stdout  # the summary block of solve_p

@@ -498,7 +498,7 @@ def test_fortran_harness(mg, tmp_path):
     o = make_seamount(64, 64, 16, relax_method="FC", solver_prec=1e-10)
     n, h, _ = o.nhydro_solve()
     for (k, r) in its:
-        assert abs(float(r) - h[int(k)]) <= 6e-4 * h[int(k)]  # E10.3 print
+        assert abs(float(r) - h[int(k)]) <= 5.1e-3 * h[int(k)]  # Fortran E10.3: 0.dddE+ee, three significant digits
     sp2 = float(re.search(r"sum_p2 = *([0-9.E+-]+)", out.stdout).group(1))
     # p is taken after correct_uvw, unchanged by it
     assert np.isclose(sp2, (o.field("p")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-13)
@@ -506,3 +506,6 @@ def test_fortran_harness(mg, tmp_path):
     sd2 = float(re.search(r"sum_div2 = *([0-9.E+-]+)", out.stdout).group(1))
     assert np.isclose(sd2, (o.field("b")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-9)
     assert os.path.exists(tmp_path / "fort.100")  # convergence history file (mg_solvers.f90:59,72)
+    # the summary block of solve_p (mg_solvers.f90:93-96) and Fortran's E10.3 in the history lines (format 10, :99)
+    assert " --- summary ---" in out.stdout and "time spent to solve :" in out.stdout and "rescaled performance:" in out.stdout
+    assert re.search(r"ite =  1: res =  0\.\d{3}E[+-]\d{2} / conv = ", out.stdout), out.stdout[-1500:]

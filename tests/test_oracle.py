@@ -237,3 +237,39 @@ def test_multigrid_solution_equals_a_direct_solve():
     assert hist[-1] < 1e-13
     pm = o.field("p")[1:-1, 1:-1, :].ravel()
     assert np.abs(pm - direct).max() <= 1e-11 * np.abs(direct).max()
+
+
+def test_call_mask_semantics():
+    """The mask of the call (rmaska of nhydro_solve, nhydro.f90:56,72): handing compute_rhs / correct_uvw the mask that
+    nhydro_matrices got changes nothing; with bmask off a land mask still removes the w cross terms of compute_rhs
+    (mg_compute_rhs.f90:110-111) and leaves umask = vmask = 1 (:69-71)."""
+    from oracle.mgoracle import Oracle, seamount_geometry
+    nx, ny, nz = 16, 16, 8
+    rng = np.random.default_rng(2)
+    mask = np.ones((nx + 2, ny + 2)); mask[4:8, 6:11] = 0.0
+
+    def run(bmask, call_mask):
+        o = Oracle(nx, ny, nz, bmask=bmask, relax_method="FC", solver_maxiter=3)
+        for name, a in zip(("dx", "dy", "zeta", "h"), seamount_geometry(nx, ny, 1, 1, 0)):
+            o.field(name)[...] = a
+        if bmask:
+            o.field("rmask")[...] = mask
+        o.matrices(4e3, 0.0, 0.0)
+        r = np.random.default_rng(7)
+        o.field("u")[...] = r.uniform(-1, 1, o.field("u").shape)
+        o.field("v")[...] = r.uniform(-1, 1, o.field("v").shape)
+        o.field("w")[...] = r.uniform(-1, 1, o.field("w").shape)
+        if call_mask is not None:
+            o.field("rmaska")[...] = call_mask
+            o.use_call_mask(True)
+        o.nhydro_solve()
+        return o.field("b").copy(), o.field("u").copy(), o.field("w").copy()
+
+    b0, u0, w0 = run(True, None)
+    b1, u1, w1 = run(True, mask)
+    assert np.array_equal(b0, b1) and np.array_equal(u0, u1) and np.array_equal(w0, w1)
+    b2, u2, _ = run(False, None)
+    b3, u3, _ = run(False, mask)
+    assert not np.array_equal(b2, b3)            # the cross terms saw the land
+    b4, _, _ = run(False, np.ones_like(mask))
+    assert np.array_equal(b2, b4)                # an all-ones mask is the no-mask case
