@@ -10,6 +10,17 @@
 
 #include "mgx_device.h"
 
+// MGX_PV: the matrix-free colour pass rebuilds the diagonal and the tridiagonal pivots in the kernel instead of streaming
+// `bet` from HBM (relax_col_mf); -DMGX_NO_PV keeps the stored pivots for A/B measurements (same bits either way).
+#ifdef MGX_NO_PV
+#define MGX_PV 0
+#else
+#define MGX_PV 1
+#endif
+#ifndef MGX_GL
+#define MGX_GL 1
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // z-line smoother, one colour pass.  mg_relax.f90:237-305 (relax_3D_8_heart) + :308-334 (tridiag).
 // Columns of one colour never read each other (four-colour), or only through the k=1 horizontal
@@ -242,15 +253,19 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 // 2 of the 19 streams of the colour pass (16 B per updated cell).  Slots 2,4,7, the pivots and the k=1 diagonal
 // terms stay stored.  Used when the matrix came from define_matrices (not after mgx_set_field(cA)).
 // ------------------------------------------------------------------------------------------------
-template <int NZ, bool REAL, bool SNAP, int D, bool ST>
-__device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph) {
+// GL: gam(k) waits in LDS (gl: NZ rows x 64 lanes per wave) instead of registers.  At NZ = 64 x and gam together take half of
+// the 512 registers; with the in-kernel pivots on top the kernel spilled (268 B/lane of scratch) -- 32 KB of LDS per wave
+// (one wave per SIMD: 128 KB of the CU's 160 KB) frees 128 registers, and the backward sweep's reads are independent of its
+// dependency chain.
+template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false>
+__device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph, double *__restrict__ gl = nullptr) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
   else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
   const long long RS = L.RS;
   double *__restrict__ p = L.p;
   const double *__restrict__ b = L.b;
-  const double *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
+  const double *__restrict__ a1 = L.cA[0], *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
                *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet,
                *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
@@ -260,7 +275,9 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   constexpr int RO = D + 2;  // own rows are needed one row early (zy(k+1), zx(k+1))
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
   double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
-  double x[NZ], g[NZ];
+  double x[NZ], g[GL ? 1 : NZ];
+  const int lane = threadIdx.x;
+#define G_PUT(kk, v) { if (GL) gl[((kk)-1) * WAVE + lane] = (v); else g[GL ? 0 : (kk)-1] = (v); }
 
 #define NB_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
@@ -274,9 +291,13 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); o_bet[s_] = ld_stream<ST>(bet + ko_); \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); \
+    if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
     o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
+  // PV: the diagonal of the first and the last row is read (two rows of the stored slot 1), the interior rows rebuild it
+  double dg1 = 0, dgn = 0;
+  if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
     const double *__restrict__ q1 = SNAP ? L.p1 : p;
@@ -305,24 +326,42 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     }
     const int s = k % RO, n = k % RN;
     const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n];
-    if (k > 1) g[k - 1] = o_a2[s] * betp;
-    betp = o_bet[s];
+    // the eight cross coefficients of this row, rebuilt from the slopes (header comment): own slots 3,5,6,8 and the
+    // mirrored ones stored at the j+1 / i+1 neighbours
+    const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p);
+    const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p);
+    double betk;
+    if (MGX_PV) {
+      // pivots in the kernel: d(k) = cA(1,k,j,i) is minus the sum of the fourteen couplings of the row, added in the order of
+      // mg_define_matrix.f90:632-639 (bit-identical to the stored value; rows 1 and nz, which have their own formulas
+      // :619-627,:642-654, are read), then tridiag's recurrence (mg_relax.f90:322-326) -- no bet stream from HBM
+      double dk;
+      if (k == 1) dk = dg1;
+      else if (k == NZ) dk = dgn;
+      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - o_a4[s] - r_a4[n] - o_a7[s] - r_a7[n] - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;
+      if (k == 1) betk = 1.0 / dk;
+      else { const double gk = o_a2[s] * betp; G_PUT(k, gk) betk = 1.0 / (dk - o_a2[s] * gk); }
+    } else {
+      if (k > 1) G_PUT(k, o_a2[s] * betp)
+      betk = o_bet[s];
+    }
+    betp = betk;
     double rhs;
     if (k == 1) {
-      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zyjp + zy_p)) * pjp_p
-                   - (qrt * (zx_p + zxim)) * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zxip + zx_p)) * pip_p;
+      rhs = o_b[s] - c3 * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5m * pjp_p
+                   - c6 * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8m * pip_p;
       if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4;
-      xv = rhs * o_bet[s];
+      xv = rhs * betk;
     } else if (k < NZ) {
-      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0
-                   - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
-                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0
-                   - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
-      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0
+                   - c5 * pjm_m - c5m * pjp_p
+                   - c6 * pim_p - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0
+                   - c8 * pim_m - c8m * pip_p;
+      xv = (rhs - o_a2[s] * xv) * betk;
     } else {
-      rhs = o_b[s] - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m
-                   - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zx_m + zxim)) * pim_m;
-      xv = (rhs - o_a2[s] * xv) * o_bet[s];
+      rhs = o_b[s] - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5 * pjm_m
+                   - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8 * pim_m;
+      xv = (rhs - o_a2[s] * xv) * betk;
     }
     x[k - 1] = xv;
     pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
@@ -330,7 +369,8 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     zy_m = zy_0; zy_0 = zy_p; zx_m = zx_0; zx_0 = zx_p;
   }
 #pragma unroll
-  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
+  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - (GL ? gl[k * WAVE + lane] : g[GL ? 0 : k]) * x[k];
+#undef G_PUT
 
   const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
   const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
@@ -366,18 +406,19 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 }
 
 // Tall columns (nz = 128, BASELINE config 5): x and gam of 128 rows do not fit the register file next to the load rings.
-// The lower LOW rows leave the chip instead: their forward-eliminated value goes to p, and the back substitution
-// re-reads it together with a2(k+1), bet(k) to rebuild gam (+32 B per low cell); the upper NZ-LOW rows are handled
-// exactly like relax_col_mf.  Same expressions, same order: bit-identical to the reference.
+// The forward-eliminated values of the lower LOW rows wait in LDS (xf: LOW rows x 64 lanes x 8 B = 32 KB per wave, one wave per
+// SIMD = 128 KB of the CU's 160 KB) instead of going out to p and coming back; their gam is rebuilt on the way down from
+// a2(k+1) and bet(k), re-read ahead of use (addresses are known: no dependent loads).  The upper NZ-LOW rows are handled exactly
+// like relax_col_mf.  Same expressions, same order: bit-identical to the reference.
 template <int NZ, int LOW, bool REAL, bool SNAP, int D, bool ST>
-__device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i, const int jh, const int jodd, const Sides ph) {
+__device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i, const int jh, const int jodd, const Sides ph, double *__restrict__ xf) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
   else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
   const long long RS = L.RS;
   double *__restrict__ p = L.p;
   const double *__restrict__ b = L.b;
-  const double *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
+  const double *__restrict__ a1 = L.cA[0], *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4],
                *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet,
                *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
@@ -402,9 +443,12 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); o_bet[s_] = ld_stream<ST>(bet + ko_); \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); \
+    if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
     o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
+  double dg1 = 0, dgn = 0;
+  if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
     const double *__restrict__ q1 = SNAP ? L.p1 : p;
@@ -422,6 +466,7 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
   double pjp_m = 0, pjp_0 = r_pjp[1 % RN], pjp_p = 0, pip_m = 0, pip_0 = r_pip[1 % RN], pip_p = 0;
   double zy_m = 0, zy_0 = o_zy[1 % RO], zy_p = 0, zx_m = 0, zx_0 = o_zx[1 % RO], zx_p = 0;
   double xv = 0.0, betp = 0.0;
+  const int lane = threadIdx.x;
 #define FWD_ROW(k)                                                        \
   {                                                                     \
     NB_LOAD(k + 1 + D) \
@@ -433,30 +478,46 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     } \
     const int s = k % RO, n = k % RN; \
     const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n]; \
-    if (k > LOW + 1) g[k - LOW - 1] = o_a2[s] * betp; \
-    betp = o_bet[s]; \
+    const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p); \
+    const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p); \
+    double betk; \
+    if (MGX_PV) { /* pivots in the kernel, see relax_col_mf */ \
+      double dk; \
+      if (k == 1) dk = dg1; \
+      else if (k == NZ) dk = dgn; \
+      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - o_a4[s] - r_a4[n] - o_a7[s] - r_a7[n] - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m; \
+      if (k == 1) betk = 1.0 / dk; \
+      else { const double gk = o_a2[s] * betp; if (k > LOW + 1) g[k - LOW - 1] = gk; betk = 1.0 / (dk - o_a2[s] * gk); } \
+    } else { \
+      if (k > LOW + 1) g[k - LOW - 1] = o_a2[s] * betp; \
+      betk = o_bet[s]; \
+    } \
+    betp = betk; \
     double rhs; \
     if (k == 1) { \
-      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zyjp + zy_p)) * pjp_p \
-                   - (qrt * (zx_p + zxim)) * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zxip + zx_p)) * pip_p; \
+      rhs = o_b[s] - c3 * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5m * pjp_p \
+                   - c6 * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8m * pip_p; \
       if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4; \
-      xv = rhs * o_bet[s]; \
+      xv = rhs * betk; \
     } else if (k < NZ) { \
-      rhs = o_b[s] - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 \
-                   - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p \
-                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 \
-                   - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p; \
-      xv = (rhs - o_a2[s] * xv) * o_bet[s]; \
+      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 \
+                   - c5 * pjm_m - c5m * pjp_p \
+                   - c6 * pim_p - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 \
+                   - c8 * pim_m - c8m * pip_p; \
+      xv = (rhs - o_a2[s] * xv) * betk; \
     } else { \
-      rhs = o_b[s] - (qrt * (zyjp + zy_m)) * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m \
-                   - (qrt * (zxip + zx_m)) * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - (-qrt * (zx_m + zxim)) * pim_m; \
-      xv = (rhs - o_a2[s] * xv) * o_bet[s]; \
+      rhs = o_b[s] - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5 * pjm_m \
+                   - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8 * pim_m; \
+      xv = (rhs - o_a2[s] * xv) * betk; \
     } \
-    if (k > LOW) x[k - LOW - 1] = xv; else p[o + (long long)(k - 1) * RS + c] = xv; \
+    if (k > LOW) x[k - LOW - 1] = xv; else xf[(k - 1) * WAVE + lane] = xv; \
+    if (k == LOW + 1) g0 = o_a2[s] * bet_low_in; \
+    if (k == LOW) bet_low_in = betk; \
     pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p; \
     pjp_m = pjp_0; pjp_0 = pjp_p; pip_m = pip_0; pip_0 = pip_p; \
     zy_m = zy_0; zy_0 = zy_p; zx_m = zx_0; zx_0 = zx_p; \
   }
+  double g0 = 0.0, bet_low_in = 0.0;  // g0 = gam(LOW+1) = a2(LOW+1)*bet(LOW): links the register half to the LDS half
 #pragma unroll
   for (int k = 1; k <= LOW; k++) FWD_ROW(k)
 #pragma unroll
@@ -478,23 +539,25 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }             \
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }             \
   }
-#pragma unroll
-  for (int k = LOW + 1; k <= NZ; k++) STORE_ROW(k, x[k - LOW - 1])
-  // lower rows, top down: x(k) = xf(k) - gam(k+1)*x(k+1), gam(k+1) = a2(k+1)*bet(k) (mg_relax.f90:325,330)
+  // lower rows, top down: x(k) = xf(k) - gam(k+1)*x(k+1), gam(k+1) = a2(k+1)*bet(k) (mg_relax.f90:325,330).  With the pivots
+  // computed in the kernel the downward pass needs bet(k) again: the recurrence only runs upward, so bet(k), k < LOW, is
+  // re-read from the array define_matrices left in memory (same bits), together with a2(k+1), DB rows ahead of use.
   constexpr int DB = 8;
-  double r_xf[DB], r_a2[DB], r_bt[DB];
+  double r_a2[DB], r_bt[DB];
 #define LOW_LOAD(q)                                                                                       \
-  if ((q) < LOW) {                                                                                        \
+  if ((q) >= 1 && (q) < LOW) {                                                                            \
     const long long ko_ = o + (long long)(LOW - (q)-1) * RS + c;                                          \
-    r_xf[(q) % DB] = p[ko_]; r_a2[(q) % DB] = ld_stream<ST>(a2 + ko_ + RS); r_bt[(q) % DB] = ld_stream<ST>(bet + ko_); \
+    r_a2[(q) % DB] = ld_stream<ST>(a2 + ko_ + RS); r_bt[(q) % DB] = ld_stream<ST>(bet + ko_);           \
   }
 #pragma unroll
-  for (int q = 0; q < DB; q++) { LOW_LOAD(q) }
+  for (int q = 1; q < DB; q++) { LOW_LOAD(q) }
+#pragma unroll
+  for (int k = LOW + 1; k <= NZ; k++) STORE_ROW(k, x[k - LOW - 1])
   double xn = x[0];
 #pragma unroll
-  for (int q = 0; q < LOW; q++) {
-    const double gg = r_a2[q % DB] * r_bt[q % DB];
-    const double xk = r_xf[q % DB] - gg * xn;
+  for (int q = 0; q < LOW; q++) {  // row LOW - q
+    const double gg = q == 0 ? g0 : r_a2[q % DB] * r_bt[q % DB];
+    const double xk = xf[(LOW - q - 1) * WAVE + lane] - gg * xn;
     LOW_LOAD(q + DB)
     STORE_ROW(LOW - q, xk)
     xn = xk;
@@ -540,7 +603,11 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
-  if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
+  constexpr bool GL = MF && NZ == 64 && MGX_GL;  // keep in step with launch_relax_nz_d
+  if (GL) {
+    extern __shared__ double g_lds[];  // blockDim.y waves x NZ rows x 64 lanes
+    relax_col_mf<NZ, REAL, SNAP, D, ST, GL>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
+  } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
   else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }
 
@@ -565,7 +632,8 @@ __global__ __launch_bounds__(128, 1) void k_relax_tall(LevView L, int i0, int is
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
-  relax_col_mf_tall<NZ, LOW, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
+  extern __shared__ double xf_lds[];  // blockDim.y waves x LOW rows x 64 lanes
+  relax_col_mf_tall<NZ, LOW, REAL, SNAP, D, ST>(L, i, jh, jodd, ph, xf_lds + (size_t)threadIdx.y * LOW * WAVE);
 }
 
 // Lexicographic Gauss-Seidel (mg_relax.f90:116-148) on the device, EXACTLY: column (j,i) of the reference's
@@ -801,11 +869,13 @@ static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int iste
   // streaming (nontemporal) hints only when the level cannot live in the 256 MB Infinity Cache between passes:
   // measured +14 % on the 1.2 GB level 1, -20 % on the 150 MB level 2 which is otherwise re-read from cache
   const bool stream = mf && (double)L->nx * L->ny * NZ * 72.0 > 256e6;
+  // gam in LDS (GL, see relax_col_mf): 32 KB per wave of the matrix-free NZ = 64 kernel
 #define LAUNCH_NZ(MFV, STV)                                                                                              \
   {                                                                                                                       \
-    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
-    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
-    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, MFV, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);            \
+    const size_t lds = (MFV && NZ == 64 && MGX_GL) ? (size_t)by * NZ * WAVE * sizeof(double) : 0;                          \
+    if (real && snap) hipLaunchKernelGGL((k_relax_nz<NZ, true, true, D, MFV, STV>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
+    else if (real) hipLaunchKernelGGL((k_relax_nz<NZ, true, false, D, MFV, STV>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
+    else hipLaunchKernelGGL((k_relax_nz<NZ, false, false, D, MFV, STV>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);            \
   }
   if (mf && stream) LAUNCH_NZ(true, true)
   else if (mf) LAUNCH_NZ(true, false)
@@ -815,7 +885,12 @@ static void launch_relax_nz_d(hipStream_t st, const LevView *L, int i0, int iste
 template <int NZ>
 static void launch_relax_nz(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   // look-ahead depth D (rows of loads in flight)
-  constexpr int D = NZ >= 32 ? 3 : (NZ >= 8 ? 2 : 1);  // measured: NZ=16 6.3 us/pass at D=2 vs 9.3 at D=3; NZ>=32 flat for D=2..5
+  // measured: NZ=16 6.3 us/pass at D=2 vs 9.3 at D=3; NZ>=32 flat for D=2..5
+#ifdef MGX_D64
+  constexpr int D = NZ == 64 ? MGX_D64 : (NZ >= 32 ? 3 : (NZ >= 8 ? 2 : 1));
+#else
+  constexpr int D = NZ >= 32 ? 3 : (NZ >= 8 ? 2 : 1);
+#endif
 #ifdef MGX_TUNE_D
   if (NZ >= 8) {
     static const int dd = getenv("MGX_D") ? atoi(getenv("MGX_D")) : 3;
@@ -837,14 +912,22 @@ static int launch_relax_nz128(hipStream_t st, const LevView *L, int i0, int iste
   const int by = gx0 * nplanes >= 2048 ? 2 : 1;
   dim3 blk(WAVE, by), grd(gx0 * ((nplanes + by - 1) / by));
   const bool stream = (double)L->nx * L->ny * 128 * 72.0 > 256e6;
+  const size_t lds = (size_t)by * 64 * WAVE * sizeof(double);  // the lower 64 rows' forward values: 32 KB per wave
+#define LAUNCH128_ONE(RV, SV, STV)                                                                                       \
+  {                                                                                                                     \
+    static bool attr = false;                                                                                           \
+    if (!attr) { (void)hipFuncSetAttribute((const void *)k_relax_tall<128, 64, RV, SV, 3, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * WAVE * (int)sizeof(double)); attr = true; } \
+    hipLaunchKernelGGL((k_relax_tall<128, 64, RV, SV, 3, STV>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
+  }
 #define LAUNCH128(STV)                                                                                                  \
   {                                                                                                                     \
-    if (real && snap) hipLaunchKernelGGL((k_relax_tall<128, 64, true, true, 3, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
-    else if (real) hipLaunchKernelGGL((k_relax_tall<128, 64, true, false, 3, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
-    else hipLaunchKernelGGL((k_relax_tall<128, 64, false, false, 3, STV>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);            \
+    if (real && snap) LAUNCH128_ONE(true, true, STV)                                                                    \
+    else if (real) LAUNCH128_ONE(true, false, STV)                                                                      \
+    else LAUNCH128_ONE(false, false, STV)                                                                               \
   }
   if (stream) LAUNCH128(true) else LAUNCH128(false)
 #undef LAUNCH128
+#undef LAUNCH128_ONE
   return 1;
 }
 
@@ -918,13 +1001,17 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
 // returns 1 when the launched kernel also wrote the physical-boundary mirrors of p (no k_halo_phys needed)
 int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   switch (L->nz) {
+#ifndef MGX_QUICK  // -DMGX_QUICK: only the nz=64 instantiations (resource-usage checks of the level-1 kernel in seconds)
     case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
     case 4: launch_relax_nz<4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
     case 8: launch_relax_nz<8>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
     case 16: launch_relax_nz<16>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
     case 32: launch_relax_nz<32>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+#endif
     case 64: launch_relax_nz<64>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+#ifndef MGX_QUICK
     case 128: if (launch_relax_nz128(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return 1; break;
+#endif
     default: break;
   }
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, nplanes);
