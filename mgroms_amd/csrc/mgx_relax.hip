@@ -999,7 +999,9 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
 }
 
 // returns 1 when the launched kernel also wrote the physical-boundary mirrors of p (no k_halo_phys needed)
+int mgxk_relax_ks(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);  // mgx_relax_ks.hip
 int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+  if (mgxk_relax_ks(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return 1;  // mid levels: rows split over the waves of a workgroup
   switch (L->nz) {
 #ifndef MGX_QUICK  // -DMGX_QUICK: only the nz=64 instantiations (resource-usage checks of the level-1 kernel in seconds)
     case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
