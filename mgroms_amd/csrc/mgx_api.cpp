@@ -35,6 +35,7 @@ int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
+int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
@@ -488,17 +489,32 @@ int residual(int lev, double *res) {
   return 0;
 }
 
-// mg_intergrids.f90:16-72
-int fine2coarse(int lev, bool dup_r = false) {
+// mg_intergrids.f90:16-72.  with_residual: the caller is the down leg of a V-cycle, which would call compute_residual(lev)
+// right before and discards both the norm and r (mg_solvers.f90:138-142): residual and restriction then run as ONE kernel
+// that never writes r (mgx_resrest.hip), when the level has its matrix-free slopes; otherwise the two kernels in sequence.
+int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0}, none = {0, 0, 0, 0};
   bool fused = false;
+  // returns true when the fused residual+restriction kernel took the job
+  auto down = [&](const LevView *Cv, double *dst, Sides ph, double *zero) -> int {
+    if (!with_residual) return 0;
+    if (!S.exact_halos && !dup_r) {
+      TicScope ts(lev, "residual_3D_8");
+      if (mgxk_residual_restrict(S.stream, &F.v, Cv, dst, S.real, ph, zero)) { S.n_launch++; return 1; }
+    }
+    return residual(lev, nullptr) ? -1 : 0;
+  };
   if (!C.gather) {
     // closed level: the kernel also zeroes p_c and, for Fcycle, duplicates b_c into r_c (whole arrays through the mirrors)
     fused = phc.S && phc.E && phc.N && phc.W;
-    mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc, fused && dup_r ? C.v.r : nullptr, fused ? C.v.p : nullptr); S.n_launch++;
+    const int d = down(&C.v, C.v.b, phc, fused ? C.v.p : nullptr);
+    if (d < 0) return 1;
+    if (!d) { mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc, fused && dup_r ? C.v.r : nullptr, fused ? C.v.p : nullptr); S.n_launch++; }
   } else {
-    mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none, nullptr, nullptr); S.n_launch++;
+    const int d = down(&C.vs, C.vs.b, none, nullptr);
+    if (d < 0) return 1;
+    if (!d) { mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none, nullptr, nullptr); S.n_launch++; }
     const int Ng = C.nz * (C.vs.ny + 2) * (C.vs.nx + 2);
     if (S.p2p_on) {  // gather_3D (mg_gather.f90:95-174) as pushes into the members' gather buffers
       const unsigned long long seq = ++C.p2p_gseq;
@@ -558,8 +574,7 @@ int coarse2fine(int lev) {
 int vcycle(int lev1) {
   for (int lev = lev1; lev <= S.nlevs - 1; lev++) {
     CHK(relax(lev, S.par.ns_pre));
-    CHK(residual(lev, nullptr));
-    CHK(fine2coarse(lev));
+    CHK(fine2coarse(lev, false, true));  // compute_residual(lev) + fine2coarse(lev)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
@@ -573,8 +588,7 @@ int vcycle(int lev1) {
 int vcycle2(int lev1, int lev2) {
   for (int lev = lev1; lev <= lev2 - 1; lev++) {
     CHK(relax(lev, S.par.ns_pre));
-    CHK(residual(lev, nullptr));
-    CHK(fine2coarse(lev));
+    CHK(fine2coarse(lev, false, true));  // compute_residual(lev) + fine2coarse(lev)
   }
   CHK(relax(lev2, S.par.ns_coarsest));
   for (int lev = lev2 - 1; lev >= lev1; lev--) {
