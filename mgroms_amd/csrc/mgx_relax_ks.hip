@@ -163,7 +163,8 @@ extern "C" {
 int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   static const bool off = getenv("MGX_NO_KS") != nullptr, noxcd = getenv("MGX_NO_XCD") != nullptr;
   static const int nw_env = getenv("MGX_KS_NW") ? atoi(getenv("MGX_KS_NW")) : 0;
-  if (off || L->zy == nullptr || (L->nz != 32 && L->nz != 16)) return 0;
+  static const bool ks8 = getenv("MGX_NO_KS8") == nullptr;
+  if (off || L->zy == nullptr || (L->nz != 32 && L->nz != 16 && !(L->nz == 8 && ks8))) return 0;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE;
   // worth it only while a colour has fewer waves than the chip has SIMDs (1024); a bandwidth-bound level keeps one wave per column set
   if (gx0 * nplanes > 512) return 0;
@@ -180,7 +181,8 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
   }
   // measured (256x256x32 / 128x128x16, four-colour sweep): 8 waves 47.0 / 21.6 us, 4 waves 53.3 / 23.3, row by row 57.6 / 28.2
   if (L->nz == 32) { if (nw_env == 4) KS_LAUNCH(32, 4) else KS_LAUNCH(32, 8) }
-  if (nw_env == 4) KS_LAUNCH(16, 4) else KS_LAUNCH(16, 8)
+  if (L->nz == 16) { if (nw_env == 4) KS_LAUNCH(16, 4) else KS_LAUNCH(16, 8) }
+  if (nw_env == 4) KS_LAUNCH(8, 4) else KS_LAUNCH(8, 8)
 #undef KS_LAUNCH
 }
 

@@ -1,0 +1,47 @@
+#!/bin/bash
+# Capture the rocprofv3 evidence behind the numbers of DESIGN.md / bench.py for one round (run on the GPU box):
+#   gpurun -- 'bash scripts/capture_profiles.sh r02'
+# Writes raw output under gpurun_out/<round>_*/ and the summaries that are tracked under profiles/.
+# PMC counters are collected in passes of their own (FETCH_SIZE and WRITE_SIZE do not fit one pass), never together with
+# the runtime trace domains.
+set -o pipefail
+R=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+stats() {  # $1 = tag, rest = program
+  local tag=$1; shift
+  timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${R}_${tag} -- "$@" > $OUT/${R}_${tag}.log 2>&1 || return 1
+  cp $(ls $OUT/${R}_${tag}/*/*_kernel_stats.csv | head -1) $ROOT/profiles/${R}_${tag}_kernel_stats.csv
+}
+# 1. the driver's bench command (N=1 defaults)
+stats bench python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 || exit 1
+# 2. V-cycles only (no set-up noise in the averages)
+stats vcycle python3 $ROOT/scripts/profile_vcycle.py 512 512 64 FC 20 || exit 1
+# 3. BASELINE config 5's level-1 shape (nz = 128)
+stats nz128 python3 $ROOT/scripts/sweep_time.py 512 512 128 FC 10 || exit 1
+# 4. HBM traffic of the dominant kernels, same bench command, two PMC passes
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_fetch -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_write -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_write.log 2>&1 || exit 1
+python3 $ROOT/scripts/pmc_summary.py $(ls $OUT/${R}_pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${R}_pmc_write/*/*_counter_collection.csv | head -1) 16777216 > $ROOT/profiles/${R}_pmc_traffic.json || exit 1
+# 5. the reference's timer table (mg_tictoc format) of a 5-iteration solve
+cd $OUT && MGX_TICTOC=1 timeout -k 10 120 python3 - > $OUT/${R}_tictoc.log 2>&1 <<PY
+import sys
+sys.path.insert(0, "$ROOT")
+import numpy as np, torch
+import mgroms_amd as mg
+from mgroms_amd import nhydro
+from mgroms_amd.testcases import seamount_geometry, resting_column_state
+torch.cuda.set_device(0)
+nhydro.set_verbose(0)
+mg.nhydro_init(512, 512, 64, 1, 1, 0, nhydro.default_params(relax_method="FC"))
+mg.nhydro_matrices(*seamount_geometry(512, 512), None, 4e3, 0.0, 0.0)
+nhydro.compute_rhs(*resting_column_state(512, 512, 64))
+mg.solve_p(1e-12, 1)
+nhydro.set_option("tictoc", 1)
+mg.solve_p(1e-12, 5)
+nhydro.print_tictoc("$ROOT/profiles/${R}_tictoc_512x512x64_FC_5it.txt")
+mg.nhydro_clean()
+PY
+mkdir -p $OUT/profiles_${R} && cp $ROOT/profiles/${R}_* $OUT/profiles_${R}/
+ls -la $OUT/profiles_${R}/
