@@ -185,6 +185,22 @@ def test_config3_vcycle_512x512x64_bitwise(mg, golden):
     o.close()
 
 
+@pytest.mark.parametrize("nz", [64, 128])
+def test_level1_red_black_two_waves_per_block(mg, nz):
+    """The level-1 kernels with TWO waves per workgroup (512 planes x 4 j-chunks = 2048 waves: red-black at 512x512; the LDS slices of
+    gam / of the lower rows are per wave): two sweeps from p = 0, bit for bit against the oracle on 4x4 emulated ranks.
+    cmatrix='simple' makes red-black order independent, so the parallel sweep is exact."""
+    _gpu(mg, 512, 512, nz, relax_method="RB", cmatrix="simple")
+    mg.relax(1, 2)
+    p = mg.grid(1).p
+    mg.nhydro_clean()
+    o = _oracle(512, 512, nz, 4, 4, relax_method="RB", cmatrix="simple")
+    o.relax(1, 2)
+    assert np.abs(p).max() > 0
+    assert _blocks_equal(p, o, "p", 4, 4) == []
+    o.close()
+
+
 # ---- BASELINE config 4: rndtopo 1024x1024x64 -----------------------------------------------------------------------------
 def test_config4_rndtopo_1024x1024x64_bitwise(mg):
     """mg_testrndtopo's geometry (h = 0.2*Htot*U per cell, mg_setup_tests.f90:199; seeded generator of this build) at the
