@@ -88,7 +88,7 @@ int mgx_relax(int lev, int nsweeps);      /* mg_relax.f90:16-47   */
 int mgx_residual(int lev, double *res);   /* mg_relax.f90:337-383: r = b - A p, halo fill of r, *res = global ||r||_2 */
 int mgx_fine2coarse(int lev);             /* mg_intergrids.f90:16-72  */
 int mgx_coarse2fine(int lev);             /* mg_intergrids.f90:167-228 */
-int mgx_fill_halo(int lev, int field);    /* mg_mpi_exchange.f90:396-745 (p,b,r) */
+int mgx_fill_halo(int lev, int field);    /* generic fill_halo (mg_mpi_exchange.f90:10-16): p,b,r (:396-745); dx,dy,zeta,h (2D :23-352); zr,zw (nh=2 :750-1242); cA (4D :1247-1534); collective */
 /* compute_rhs / correct_uvw on the device-resident model state (mg_compute_rhs.f90:14, mg_correct_uvw.f90:15) */
 int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask);
 

@@ -241,7 +241,8 @@ int rccl_allreduce_hook(void *, double *buf, int n) { return mgxr_allreduce(S.st
 int rccl_allgather_hook(void *, const int *group, int ng, const double *sb, double *rb, int cnt) { return mgxr_allgather(S.stream, group, ng, sb, rb, cnt); }
 
 // fill_halo_3D_relax / fill_halo_3D for the JS fields p,b,r (nh = 1): mg_mpi_exchange.f90:396-745
-int fill_halo_js(Level &L, double *a, bool phys_done = false) {
+// xonly: fill_halo_4D's rule (mg_mpi_exchange.f90:1247-1534): nothing but the exchange with existing neighbours
+int fill_halo_js(Level &L, double *a, bool phys_done = false, bool xonly = false) {
   S.n_halo++;
   const int *nb = L.neighb;
   Sides ph = {nb[0] < 0, nb[1] < 0, nb[2] < 0, nb[3] < 0};
@@ -260,6 +261,7 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false) {
     const int side1[4] = {0, 0, 2, 2}, side2[4] = {3, 1, 1, 3};  // SW:(S,W) SE:(S,E) NE:(N,E) NW:(N,W)
     for (int c = 0; c < 4; c++) {
       if (nb[4 + c] < 0) { if (nb[side1[c]] >= 0) m[c] = 1; else if (nb[side2[c]] >= 0) m[c] = 2; }
+      if (xonly) m[c] = 0;
       any |= m[c] != 0;
     }
   }
@@ -1191,12 +1193,25 @@ int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); C
 int mgx_residual(int lev, double *res) { NEED_LEV(lev); double r; CHK(residual(lev, &r)); if (res) *res = r; return 0; }
 int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); CHK(sync_stream()); return 0; }
 int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); CHK(sync_stream()); return 0; }
+// the generic fill_halo(lev, field) of mg_mpi_exchange.f90:10-16: 3-D solver fields p, b, r (fill_halo_3D[_relax], nh = 1), the 2-D
+// geometry dx, dy, zeta, h (fill_halo_2D), zr / zw (fill_halo_3D with nh = 2: extrapolation at physical sides, :956-964) and the
+// 4-D cA (fill_halo_4D: neighbour exchange only).  Collective over the ranks.
 int mgx_fill_halo(int lev, int field) {
   NEED_LEV(lev);
   Level &L = S.lev[lev - 1];
-  double *a = field == MGX_P ? L.v.p : (field == MGX_B ? L.v.b : (field == MGX_R ? L.v.r : nullptr));
-  if (!a) return fail("fill_halo: field %d is not one of p,b,r", field);
-  CHK(fill_halo_js(L, a));
+  switch (field) {
+    case MGX_P: CHK(fill_halo_js(L, L.v.p)); break;
+    case MGX_B: CHK(fill_halo_js(L, L.v.b)); L.b_halo_stale = false; break;
+    case MGX_R: CHK(fill_halo_js(L, L.v.r)); L.r_halo_stale = false; break;
+    case MGX_CA: for (int s = 0; s < 8; s++) CHK(fill_halo_js(L, L.v.cA[s], true, true)); break;
+    case MGX_DX: CHK(rl_fill_halo(L, L.g.dx, 1, 1, 0)); break;
+    case MGX_DY: CHK(rl_fill_halo(L, L.g.dy, 1, 1, 0)); break;
+    case MGX_ZETA: CHK(rl_fill_halo(L, L.g.zeta, 1, 1, 0)); break;
+    case MGX_H: CHK(rl_fill_halo(L, L.g.h, 1, 1, 0)); break;
+    case MGX_ZR: CHK(rl_fill_halo(L, L.g.zr, L.nz, 2, 0)); break;
+    case MGX_ZW: CHK(rl_fill_halo(L, L.g.zw, L.nz + 1, 2, 0)); break;
+    default: return fail("fill_halo: field %d has no halo rule (p, b, r, cA, dx, dy, zeta, h, zr, zw)", field);
+  }
   CHK(sync_stream());
   return 0;
 }

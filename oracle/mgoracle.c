@@ -1252,10 +1252,24 @@ void mgo_relax(void *h, int lev, int nsweeps) { relax_level((oworld *)h, lev, ns
 double mgo_residual(void *h, int lev) { return compute_residual((oworld *)h, lev); }
 void mgo_fine2coarse(void *h, int lev) { fine2coarse((oworld *)h, lev); }
 void mgo_coarse2fine(void *h, int lev) { coarse2fine((oworld *)h, lev); }
+/* the generic fill_halo(lev, field) (mg_mpi_exchange.f90:10-16): 3-D solver fields (nh=1), 2-D geometry, zr / zw (nh=2), cw, and the
+ * 4-D cA (id 3: neighbour exchange only, :1247-1534) */
 void mgo_fill_halo(void *h, int lev, int id) {
   oworld *W = (oworld *)h;
-  field_fn f = id == 0 ? f_p : (id == 1 ? f_b : f_r);
-  fill_halo_all(W, lev - 1, f, HD(W->rk[0].lev[lev - 1].nz, 1, 0));
+  const int nz = W->rk[0].lev[lev - 1].nz;
+  switch (id) {
+    case 0: fill_halo_all(W, lev - 1, f_p, HD(nz, 1, 0)); break;
+    case 1: fill_halo_all(W, lev - 1, f_b, HD(nz, 1, 0)); break;
+    case 2: fill_halo_all(W, lev - 1, f_r, HD(nz, 1, 0)); break;
+    case 3: { halo_desc d = HD(8 * nz, 1, 0); for (int r = 0; r < W->nranks; r++) halo_phase2_exchange_only(W, r, lev - 1, f_cA, &d); break; }
+    case 4: fill_halo_all(W, lev - 1, f_dx, HD(1, 1, 0)); break;
+    case 5: fill_halo_all(W, lev - 1, f_dy, HD(1, 1, 0)); break;
+    case 6: fill_halo_all(W, lev - 1, f_zeta, HD(1, 1, 0)); break;
+    case 7: fill_halo_all(W, lev - 1, f_h, HD(1, 1, 0)); break;
+    case 8: fill_halo_all(W, lev - 1, f_zr, HD(nz, 2, 0)); break;
+    case 9: fill_halo_all(W, lev - 1, f_zw, HD(nz + 1, 2, 0)); break;
+    default: break;
+  }
 }
 
 /* nhydro.f90:53-102 nhydro_solve: returns iteration count */

@@ -123,6 +123,17 @@ def main():
     want = lambda q: float(q if q >= 0 else rank)
     assert np.all(ph[1:-1, 0, :] == want(nbr[0])) and np.all(ph[-1, 1:-1, :] == want(nbr[1])), rank
     assert np.all(ph[1:-1, -1, :] == want(nbr[2])) and np.all(ph[0, 1:-1, :] == want(nbr[3])), rank
+    # the generic fill_halo of mg_mpi_exchange.f90:10-16 on the other array kinds: 2-D (dx), nh = 2 with the linear extrapolation
+    # at physical sides (zr), and the 4-D cA (neighbour exchange only); rank-dependent random contents, halos compared with the
+    # oracle's emulated exchange.  Last: set_field(cA) replaces the solver's matrix.
+    if method == "FC":
+        for name in ("dx", "zr", "cA"):
+            for r in range(o.nranks):
+                a = o.field(name, 1, r)
+                a[...] = np.random.default_rng(77 + r).standard_normal(a.shape)
+            g1.set(name, o.field(name, 1, rank))
+            mg.fill_halo(1, name); o.fill_halo(1, name)
+            assert np.array_equal(g1.get(name), o.field(name, 1, rank)), (rank, name)
     stamp("checks")
     mg.nhydro_clean()
     dist.barrier()

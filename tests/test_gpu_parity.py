@@ -82,6 +82,22 @@ def test_residual_and_norm(mg):
         assert abs(res - reso) <= 1e-13 * reso
 
 
+def test_generic_fill_halo(mg):
+    # fill_halo(lev, field) for the array kinds beyond p/b/r (mg_mpi_exchange.f90:10-16): 2-D mirror, nh=2 extrapolation (zr, zw)
+    o = _setup(mg, 32, 16, 8)
+    r = np.random.default_rng(12)
+    for lev in (1, 2):
+        g = mg.grid(lev)
+        for name in ("dx", "h", "zr", "zw"):
+            a = r.standard_normal(g._shape(name))
+            g.set(name, a); o.field(name, lev)[...] = a
+            mg.fill_halo(lev, name); o.fill_halo(lev, name)
+            assert np.array_equal(g.get(name), o.field(name, lev)), (lev, name)
+    from mgroms_amd._lib import MgxError
+    with pytest.raises(MgxError):
+        mg.fill_halo(1, "cw")
+
+
 @pytest.mark.parametrize("cmatrix", ["real", "simple"])
 def test_relax_fc_bitwise(mg, cmatrix):
     nx, ny, nz = 32, 32, 16
