@@ -89,6 +89,10 @@ int mgx_residual(int lev, double *res);   /* mg_relax.f90:337-383: r = b - A p, 
 int mgx_fine2coarse(int lev);             /* mg_intergrids.f90:16-72  */
 int mgx_coarse2fine(int lev);             /* mg_intergrids.f90:167-228 */
 int mgx_fill_halo(int lev, int field);    /* generic fill_halo (mg_mpi_exchange.f90:10-16): p,b,r (:396-745); dx,dy,zeta,h (2D :23-352); zr,zw (nh=2 :750-1242); cA (4D :1247-1534); collective */
+/* testgalerkin(lev) (mg_solvers.f90:203-288): *norm_c = <p,A p> on level lev, *norm_f = <I p, A I p> on level lev-1 (the reference
+ * prints norm_c, norm_f/4 and norm_c/norm_f*4).  The coarse field is grid(lev)%p as the caller set it (the reference draws
+ * it with random_number); b of both levels is zeroed. */
+int mgx_testgalerkin(int lev, double *norm_c, double *norm_f);
 /* compute_rhs / correct_uvw on the device-resident model state (mg_compute_rhs.f90:14, mg_correct_uvw.f90:15) */
 int mgx_compute_rhs(const double *u, const double *v, const double *w, const double *rmask);
 

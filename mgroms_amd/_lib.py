@@ -44,6 +44,7 @@ _SIGS = {
     "mgx_coarse2fine": (C.c_int, [C.c_int]),
     "mgx_fill_halo": (C.c_int, [C.c_int, C.c_int]),
     "mgx_compute_rhs": (C.c_int, [_DP, _DP, _DP, _DP]),
+    "mgx_testgalerkin": (C.c_int, [C.c_int, _DP, _DP]),
     "mgx_nlevs": (C.c_int, []),
     "mgx_level_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgx_level_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),

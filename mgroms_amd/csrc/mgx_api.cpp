@@ -34,6 +34,7 @@ int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
+void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
@@ -1213,6 +1214,35 @@ int mgx_fill_halo(int lev, int field) {
     default: return fail("fill_halo: field %d has no halo rule (p, b, r, cA, dx, dy, zeta, h, zr, zw)", field);
   }
   CHK(sync_stream());
+  return 0;
+}
+
+// testgalerkin(lev) (mg_solvers.f90:203-288): energy of a coarse field under the coarse operator against the energy of its
+// interpolation under the fine one.  The reference fills grid(lev)%p with random_number; here the caller provides it
+// (mgx_set_field(lev, MGX_P, ...)), everything after that is the reference's sequence.  b of both levels is zeroed, as there.
+int mgx_testgalerkin(int lev, double *norm_c, double *norm_f) {
+  NEED_LEV(lev);
+  if (lev < 2) return fail("testgalerkin(%d): needs a finer level lev-1", lev);
+  if (!S.have_matrix) return fail("testgalerkin: no matrix");
+  double nc = 0, nf = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    Level &L = S.lev[pass == 0 ? lev - 1 : lev - 2];
+    const int l = pass == 0 ? lev : lev - 1;
+    if (pass == 0) CHK(fill_halo_js(L, L.v.p));                                   // call fill_halo(lev,grid(lev)%p)
+    else {
+      HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));        // grid(lev-1)%p = 0
+      CHK(coarse2fine(l));                                                         // interpolate p to r and add r to p
+    }
+    HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));          // grid(.)%b = 0
+    CHK(residual(l, nullptr));
+    mgxk_dot(S.stream, &L.v, L.v.p, L.v.r, S.d_partial, S.d_scalar); S.n_launch += 2;  // norm(lev,p,r,...) -> global_sum
+    double s; CHK(global_sum(L, &s));
+    (pass == 0 ? nc : nf) = s;
+  }
+  if (S.verbose && S.rank == 0)
+    printf(" ======== lev %12d ===========\n norm coarse = %24.16E\n norm fine   = %24.16E\n ratio       = %24.16E\n", lev, nc, nf / 4, nc / nf * 4);
+  if (norm_c) *norm_c = nc;
+  if (norm_f) *norm_f = nf;
   return 0;
 }
 

@@ -208,6 +208,29 @@ __global__ __launch_bounds__(256) void k_sumsq(LevView L, const double *__restri
   }
 }
 
+// inner product of the interiors of two JS fields (norm(lev,x,y), mg_solvers.f90:180-200)
+__global__ __launch_bounds__(256) void k_dot(LevView L, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ partial) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x;
+  const int i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  double acc = 0.0;
+  if (jh < (L.ny >> 1) && i <= L.nx) {
+    const int c = blockIdx.z == 0 ? L.HO + jh : L.EO + jh + 1;
+    const long long o = (long long)i * L.plane + c;
+    for (int k = 0; k < L.nz; k++) acc += a[o + (long long)k * L.RS] * b[o + (long long)k * L.RS];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double red[16];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, w = tid >> 6;
+  if ((tid & 63) == 0) red[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    for (int q = 0; q < nw; q++) s += red[q];
+    partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
 // second stage: one block sums the partials in index order -> out[0]
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial, int n, double *__restrict__ out) {
   __shared__ double red[256];
@@ -599,6 +622,11 @@ void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *ou
 void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *partial, double *out) {
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
   hipLaunchKernelGGL(k_sumsq, grd, blk, 0, st, *L, a, partial);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
+}
+void mgxk_dot(hipStream_t st, const LevView *L, const double *a, const double *b, double *partial, double *out) {
+  dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
+  hipLaunchKernelGGL(k_dot, grd, blk, 0, st, *L, a, b, partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {

@@ -177,6 +177,13 @@ def fill_halo(lev, name):
     check(lib().mgx_fill_halo(lev, FIELD[name]))
 
 
+def testgalerkin(lev):
+    """testgalerkin(lev) (mg_solvers.f90:203): returns (norm_c, norm_f) for the coarse field found in grid(lev).p."""
+    a, b = C.c_double(), C.c_double()
+    check(lib().mgx_testgalerkin(lev, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def nlevs():
     return lib().mgx_nlevs()
 

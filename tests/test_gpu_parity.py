@@ -82,6 +82,24 @@ def test_residual_and_norm(mg):
         assert abs(res - reso) <= 1e-13 * reso
 
 
+def test_testgalerkin_through_the_abi(mg):
+    # testgalerkin (mg_solvers.f90:203-288) through the C ABI against the same sequence on the oracle: a smooth coarse field,
+    # <xc, Ac xc> and <I xc, Af I xc> (the reference prints norm_c, norm_f/4 and norm_c/norm_f*4); the two energies agree within 10 %
+    o = _setup(mg, 32, 32, 16)
+    i, j, k = np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij")
+    xc = np.sin(np.pi * (i + 0.5) / 16) ** 2 * np.sin(np.pi * (j + 0.5) / 16) ** 2 * np.sin(np.pi * (k + 0.5) / 8)
+    pc = np.zeros(mg.grid(2)._shape("p")); pc[1:-1, 1:-1, :] = xc
+    mg.grid(2).set("p", pc)
+    nc, nf = mg.nhydro.testgalerkin(2)
+    o.field("p", 2)[...] = pc; o.fill_halo(2, "p"); o.field("b", 2)[...] = 0; o.residual(2)
+    nco = (o.field("p", 2)[1:-1, 1:-1, :] * o.field("r", 2)[1:-1, 1:-1, :]).sum()
+    o.field("p", 1)[...] = 0; o.coarse2fine(1); o.field("b", 1)[...] = 0; o.residual(1)
+    nfo = (o.field("p", 1)[1:-1, 1:-1, :] * o.field("r", 1)[1:-1, 1:-1, :]).sum()
+    assert abs(nc - nco) <= 1e-12 * abs(nco) and abs(nf - nfo) <= 1e-12 * abs(nfo)
+    assert np.array_equal(mg.grid(1).p, o.field("p", 1))
+    assert 0.85 < nf / nc < 1.1
+
+
 def test_generic_fill_halo(mg):
     # fill_halo(lev, field) for the array kinds beyond p/b/r (mg_mpi_exchange.f90:10-16): 2-D mirror, nh=2 extrapolation (zr, zw)
     o = _setup(mg, 32, 16, 8)
