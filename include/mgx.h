@@ -105,6 +105,8 @@ int mgx_level_info(int lev, int *out);
  * (mg_grids.f90:468-738) for any rank, usable before mgx_init and without a GPU.  out: 20 ints per level =
  * nx,ny,nz,npx,npy,incx,incy,gather,ngx,ngy,key,color, neighbours S,E,N,W,SW,SE,NE,NW.  Returns nlevs, or -1. */
 int mgx_level_table(int nx, int ny, int nz, int npx, int npy, int rank, int nsmall, int maxlev, int *out);
+/* In a multi-rank run mgx_get_field(lev, MGX_R | MGX_B, ...) is COLLECTIVE when the neighbour part of that field's halo is still
+ * pending (the cycle defers the exchanges nothing reads): every rank must ask, as with mgx_fill_halo. */
 int mgx_get_field(int lev, int field, double *host);
 int mgx_set_field(int lev, int field, const double *host);
 
@@ -170,7 +172,8 @@ int mgx_counters(long long *out);
  * no host step, no callback.  Set-up is collective: every rank calls mgx_p2p_prepare (after mgx_init), the handle blobs
  * (mgx_p2p_handle_bytes() each) are all-gathered in rank order by the caller, every rank calls mgx_p2p_connect with
  * the concatenation.  mgx_set_option("p2p", 0|1) switches between this transport and the exchange callback (all
- * ranks together).  A neighbour that never shows up makes the next synchronising call fail (5 s device time-out). */
+ * ranks together).  A neighbour that never shows up makes the next synchronising call fail (5 s device time-out) and switches the
+ * pushes off on this rank: the sequence numbers of the two sides are then apart, so the ranks must agree and switch together. */
 int mgx_p2p_handle_bytes(void);
 int mgx_p2p_prepare(void *handles_out);
 int mgx_p2p_connect(const void *all_handles, int nranks);

@@ -841,7 +841,15 @@ void p2p_release() {
 // stream synchronise + the peer-to-peer error word (a neighbour that never raised its flag)
 int sync_stream() {
   HIPCHK(hipStreamSynchronize(S.stream));
-  if (S.p2p_err && *S.p2p_err) { *S.p2p_err = 0; return fail("peer-to-peer halo exchange timed out waiting for a neighbour"); }
+  if (S.p2p_err && *S.p2p_err) {
+    // a missed exchange leaves the per-level sequence numbers of the two neighbours apart for good: every later exchange would
+    // time out as well (5 s each).  The pushes are switched off on this rank; the caller has to re-establish them collectively
+    // (mgx_set_option("p2p", 1) on every rank after agreeing, or a new mgx_init + mgx_p2p_connect).
+    *S.p2p_err = 0;
+    S.p2p_on = false;
+    return fail("peer-to-peer halo exchange timed out waiting for a neighbour; the peer-to-peer transport is now OFF on this rank "
+                "(halos fall back to the hooks): all ranks must switch together before going on");
+  }
   return 0;
 }
 
