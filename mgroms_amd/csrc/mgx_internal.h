@@ -19,6 +19,11 @@ struct LevView {
   double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
   double *p1w;      // when set: the colour pass also writes its new k=1 values here (= the snapshot of the NEXT sweep)
   double *zy, *zx;  // slopes ZY, ZX (JS layout) for the matrix-free cross terms; nullptr = use the stored slots
+  // interior rows of slots 4 and 7 rebuilt in the kernel (mg_define_matrix.f90:532-534,549-551) from the interface depths:
+  // zw in a JS-like layout with nz+1 rows per plane (planew = (nz+1)*RS) and four 2-D factor arrays, one row of RS per plane:
+  // m4 = dx(j,i)+dx(j-1,i), d4 = hlf*(dy(j,i)+dy(j-1,i)), m7 = dy(j,i)+dy(j,i-1), d7 = hlf*(dx(j,i)+dx(j,i-1)).  nullptr = stored slots.
+  double *zw, *m4, *d4, *m7, *d7;
+  long long planew;
 };
 
 __host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }

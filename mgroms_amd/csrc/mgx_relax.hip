@@ -20,6 +20,20 @@
 #ifndef MGX_GL
 #define MGX_GL 1
 #endif
+// The j-1 and j+1 neighbours of a column sit side by side in the other half-row (jp = jm + 1): ONE 16-byte load per lane fetches
+// both, instead of two 8-byte loads whose wave-wide footprints overlap by 63/64 (half the wave-level requests for these streams;
+// 8-byte alignment only: gfx950 global loads do not need natural alignment)
+#ifndef MGX_PAIR
+#define MGX_PAIR 1
+#endif
+#ifndef MGX_ZW
+#define MGX_ZW 1
+#endif
+#if MGX_PAIR
+#define LD_PAIR(ptr, A, B) { double2 t2_; __builtin_memcpy(&t2_, (ptr), 16); A = t2_.x; B = t2_.y; }
+#else
+#define LD_PAIR(ptr, A, B) { A = (ptr)[0]; B = (ptr)[1]; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // z-line smoother, one colour pass.  mg_relax.f90:237-305 (relax_3D_8_heart) + :308-334 (tridiag).
@@ -257,7 +271,12 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 // the 512 registers; with the in-kernel pivots on top the kernel spilled (268 B/lane of scratch) -- 32 KB of LDS per wave
 // (one wave per SIMD: 128 KB of the CU's 160 KB) frees 128 registers, and the backward sweep's reads are independent of its
 // dependency chain.
-template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false>
+// ZW: the interior rows of slots 4 and 7 (own and of the j+1 / i+1 neighbour: four streams) are rebuilt from the interface depths
+// zw of the column and of its four face neighbours (three streams: own, the j-1/j+1 pair in one 16-byte load, i-1 and i+1 shared
+// with the neighbouring planes' passes) with the reference's expressions (mg_define_matrix.f90:532-534,549-551; the 2-D factors come
+// precomputed, k_zw_js): bit-identical values, one stream less, four more fp64 divisions per row under the loads.  Rows 1 and nz
+// have other formulas (:361-372,:577-590): they read the stored slots.
+template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false, bool ZW = false>
 __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph, double *__restrict__ gl = nullptr) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
@@ -276,28 +295,44 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
   double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
   double x[NZ], g[GL ? 1 : NZ];
+  double w_o[RO], w_jm[RO], w_jp[RO], w_im[RO], w_ip[RO];  // ZW: zw of the column and of its face neighbours, rows k .. k+1+D
+  const double *__restrict__ zw = L.zw;
+  const long long wo = (long long)i * L.planew, wom = wo - L.planew, wop = wo + L.planew;
   const int lane = threadIdx.x;
 #define G_PUT(kk, v) { if (GL) gl[((kk)-1) * WAVE + lane] = (v); else g[GL ? 0 : (kk)-1] = (v); }
 
 #define NB_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ro_ = (long long)((q)-1) * RS; const int s_ = (q) % RN;      \
-    r_pjm[s_] = p[o + ro_ + jm]; r_pim[s_] = p[om + ro_ + c];                    \
-    r_pjp[s_] = p[o + ro_ + jp]; r_pip[s_] = p[op + ro_ + c];                    \
-    r_zyjm[s_] = *(zy + o + ro_ + jm); r_zyjp[s_] = *(zy + o + ro_ + jp); \
+    LD_PAIR(p + o + ro_ + jm, r_pjm[s_], r_pjp[s_]) r_pim[s_] = p[om + ro_ + c];  \
+    r_pip[s_] = p[op + ro_ + c];                                                 \
+    LD_PAIR(zy + o + ro_ + jm, r_zyjm[s_], r_zyjp[s_])                            \
     r_zxim[s_] = *(zx + om + ro_ + c); r_zxip[s_] = *(zx + op + ro_ + c); \
-    r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c);      \
+    if (!ZW) { r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c); }  \
+    else if ((q) >= 2) { LD_PAIR(zw + wo + ro_ + jm, w_jm[s_], w_jp[s_]) w_im[s_] = zw[wom + ro_ + c]; w_ip[s_] = zw[wop + ro_ + c]; } \
   }
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); \
+    if (!ZW) { o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); } \
+    else if ((q) >= 2) w_o[s_] = ld_stream<ST>(zw + wo + (long long)((q)-1) * RS + c); \
     if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
     o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
   // PV: the diagonal of the first and the last row is read (two rows of the stored slot 1), the interior rows rebuild it
   double dg1 = 0, dgn = 0;
   if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
+  // ZW: stored slots 4 and 7 of the first and the last row, and the per-column factors of the interior formula
+  double a4_1 = 0, a4j_1 = 0, a7_1 = 0, a7i_1 = 0, a4_n = 0, a4j_n = 0, a7_n = 0, a7i_n = 0, m4c = 0, m4p = 0, d4c = 1, d4p = 1, m7c = 0, m7p = 0, d7c = 1, d7p = 1;
+  if (ZW) {
+    const long long rn = (long long)(NZ - 1) * RS;
+    a4_1 = a4[o + c]; a4j_1 = a4[o + jp]; a7_1 = a7[o + c]; a7i_1 = a7[op + c];
+    a4_n = a4[o + rn + c]; a4j_n = a4[o + rn + jp]; a7_n = a7[o + rn + c]; a7i_n = a7[op + rn + c];
+    const long long q2 = (long long)i * RS;
+    m4c = L.m4[q2 + c]; m4p = L.m4[q2 + jp]; d4c = L.d4[q2 + c]; d4p = L.d4[q2 + jp];
+    m7c = L.m7[q2 + c]; m7p = L.m7[q2 + RS + c]; d7c = L.d7[q2 + c]; d7p = L.d7[q2 + RS + c];
+  }
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
     const double *__restrict__ q1 = SNAP ? L.p1 : p;
@@ -330,6 +365,18 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     // mirrored ones stored at the j+1 / i+1 neighbours
     const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p);
     const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p);
+    double a4o, a4jp, a7o, a7ip;  // slots 4 and 7 of the cell and of its j+1 / i+1 neighbour
+    if (!ZW) { a4o = o_a4[s]; a4jp = r_a4[n]; a7o = o_a7[s]; a7ip = r_a7[n]; }
+    else if (k == 1) { a4o = a4_1; a4jp = a4j_1; a7o = a7_1; a7ip = a7i_1; }
+    else if (k == NZ) { a4o = a4_n; a4jp = a4j_n; a7o = a7_n; a7ip = a7i_n; }
+    else {
+      const int sp = (k + 1) % RO, np = (k + 1) % RN;
+      const double wo0 = w_o[s], wop1 = w_o[sp];
+      a4o = (qrt * (wop1 - wo0 + w_jm[np] - w_jm[n]) * m4c) / d4c;
+      a4jp = (qrt * (w_jp[np] - w_jp[n] + wop1 - wo0) * m4p) / d4p;
+      a7o = (qrt * (wop1 - wo0 + w_im[np] - w_im[n]) * m7c) / d7c;
+      a7ip = (qrt * (w_ip[np] - w_ip[n] + wop1 - wo0) * m7p) / d7p;
+    }
     double betk;
     if (MGX_PV) {
       // pivots in the kernel: d(k) = cA(1,k,j,i) is minus the sum of the fourteen couplings of the row, added in the order of
@@ -338,7 +385,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
       double dk;
       if (k == 1) dk = dg1;
       else if (k == NZ) dk = dgn;
-      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - o_a4[s] - r_a4[n] - o_a7[s] - r_a7[n] - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;
+      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - a4o - a4jp - a7o - a7ip - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;
       if (k == 1) betk = 1.0 / dk;
       else { const double gk = o_a2[s] * betp; G_PUT(k, gk) betk = 1.0 / (dk - o_a2[s] * gk); }
     } else {
@@ -348,19 +395,19 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     betp = betk;
     double rhs;
     if (k == 1) {
-      rhs = o_b[s] - c3 * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5m * pjp_p
-                   - c6 * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8m * pip_p;
+      rhs = o_b[s] - c3 * pjm_p - a4o * pjm_0 - a4jp * pjp_0 - c5m * pjp_p
+                   - c6 * pim_p - a7o * pim_0 - a7ip * pip_0 - c8m * pip_p;
       if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4;
       xv = rhs * betk;
     } else if (k < NZ) {
-      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0
+      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0
                    - c5 * pjm_m - c5m * pjp_p
-                   - c6 * pim_p - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0
+                   - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0
                    - c8 * pim_m - c8m * pip_p;
       xv = (rhs - o_a2[s] * xv) * betk;
     } else {
-      rhs = o_b[s] - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5 * pjm_m
-                   - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8 * pim_m;
+      rhs = o_b[s] - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0 - c5 * pjm_m
+                   - c6m * pip_m - a7o * pim_0 - a7ip * pip_0 - c8 * pim_m;
       xv = (rhs - o_a2[s] * xv) * betk;
     }
     x[k - 1] = xv;
@@ -604,9 +651,10 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
   constexpr bool GL = MF && NZ == 64 && MGX_GL;  // keep in step with launch_relax_nz_d
+  constexpr bool ZW = MF && NZ == 64 && MGX_ZW;
   if (GL) {
     extern __shared__ double g_lds[];  // blockDim.y waves x NZ rows x 64 lanes
-    relax_col_mf<NZ, REAL, SNAP, D, ST, GL>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
+    relax_col_mf<NZ, REAL, SNAP, D, ST, GL, ZW>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
   } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
   else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }

@@ -6,7 +6,7 @@
 // loads per fine cell (every neighbour value fetched again by every lane that needs it), write r and read it back, and
 // stream the stored diagonal.  Here one lane owns one fine plane of a COARSE column (two fine columns jA, jB; lanes 0-31 of a
 // wave take plane iA, lanes 32-63 plane iB of the same 32 coarse columns), walks it bottom to top with three-row windows in
-// registers, shares the pair's p / slope / coefficient values between its two residuals (29 loads per row = 14.5 per
+// registers, shares the pair's p / slope / coefficient values between its two residuals (24 loads per row = 12 per
 // cell), rebuilds the diagonal from the couplings (as the smoother does, mgx_relax.hip), and the 8-cell sum is closed with
 // the partner lane's two values (one cross-lane exchange per row): no r traffic, no diagonal stream, one launch.
 // Measured (rocprofv3, MI355X): 512x512x64 250 us against 279 + 36 for the two kernels; 256x256x32 45 against 47 + 13.
@@ -25,13 +25,12 @@ struct RowW {
   double P[4];      // p of the own plane at j = jA-1, jA, jB, jB+1
   double Pm[2];     // p of plane i-1 at jA, jB
   double Pp[2];     // p of plane i+1
-  double ZY[2];     // own slopes at jA, jB
-  double ZX[2];
+  double ZY4[4];    // slopes zy of the own plane at jA-1, jA, jB, jB+1 (the inner two with their k-1 / k+1 neighbours)
+  double ZX[2];     // own slopes zx at jA, jB
   double A2[2];     // slot 2 (couples k with k-1)
 };
 // values needed at the row itself only
 struct RowR {
-  double ZYn[2];    // zy at jA-1, jB+1
   double ZXm[2];    // zx of plane i-1 at jA, jB
   double ZXp[2];    // zx of plane i+1
   double A4[3];     // slot 4 at jA, jB, jB+1
@@ -45,23 +44,27 @@ struct Geo {
   int c[4];             // row positions of jA-1, jA, jB, jB+1
 };
 
+// jA-1 and jB sit side by side in the even half-row, jA and jB+1 in the odd one (c[2] = c[0] + 1, c[3] = c[1] + 1): one 16-byte
+// load per pair instead of two 8-byte loads whose wave-wide footprints overlap
+#define LD_PAIR(ptr, A, B) { double2 t2_; __builtin_memcpy(&t2_, (ptr), 16); A = t2_.x; B = t2_.y; }
 __device__ __forceinline__ void load_w(RowW &w, const LevView &F, const Geo &g, const long long ro) {
   const double *__restrict__ p = F.p, *__restrict__ zy = F.zy, *__restrict__ zx = F.zx, *__restrict__ a2 = F.cA[1];
-#pragma unroll
-  for (int jx = 0; jx < 4; jx++) w.P[jx] = p[g.o + ro + g.c[jx]];
+  LD_PAIR(p + g.o + ro + g.c[0], w.P[0], w.P[2])
+  LD_PAIR(p + g.o + ro + g.c[1], w.P[1], w.P[3])
+  LD_PAIR(zy + g.o + ro + g.c[0], w.ZY4[0], w.ZY4[2])
+  LD_PAIR(zy + g.o + ro + g.c[1], w.ZY4[1], w.ZY4[3])
 #pragma unroll
   for (int jj = 0; jj < 2; jj++) {
     const long long e = g.o + ro + g.c[jj + 1];
     w.Pm[jj] = p[g.om + ro + g.c[jj + 1]]; w.Pp[jj] = p[g.op + ro + g.c[jj + 1]];
-    w.ZY[jj] = zy[e]; w.ZX[jj] = zx[e]; w.A2[jj] = a2[e];
+    w.ZX[jj] = zx[e]; w.A2[jj] = a2[e];
   }
 }
 
 __device__ __forceinline__ void load_r(RowR &r, const LevView &F, const Geo &g, const long long ro) {
-  const double *__restrict__ b = F.b, *__restrict__ zy = F.zy, *__restrict__ zx = F.zx, *__restrict__ a4 = F.cA[3], *__restrict__ a7 = F.cA[6];
-  r.ZYn[0] = zy[g.o + ro + g.c[0]]; r.ZYn[1] = zy[g.o + ro + g.c[3]];
-#pragma unroll
-  for (int jx = 1; jx < 4; jx++) r.A4[jx - 1] = a4[g.o + ro + g.c[jx]];
+  const double *__restrict__ b = F.b, *__restrict__ zx = F.zx, *__restrict__ a4 = F.cA[3], *__restrict__ a7 = F.cA[6];
+  LD_PAIR(a4 + g.o + ro + g.c[1], r.A4[0], r.A4[2])
+  r.A4[1] = a4[g.o + ro + g.c[2]];
 #pragma unroll
   for (int jj = 0; jj < 2; jj++) {
     const int c = g.c[jj + 1];
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
       const double pjp_m = Wm.P[jj + 2], pjp_0 = W0.P[jj + 2], pjp_p = Wp.P[jj + 2];                                         \
       const double pim_m = Wm.Pm[jj], pim_0 = W0.Pm[jj], pim_p = Wp.Pm[jj];                                                  \
       const double pip_m = Wm.Pp[jj], pip_0 = W0.Pp[jj], pip_p = Wp.Pp[jj];                                                  \
-      const double zy_m = Wm.ZY[jj], zy_p = Wp.ZY[jj], zx_m = Wm.ZX[jj], zx_p = Wp.ZX[jj];                                   \
-      const double zyjm = jj == 0 ? R0.ZYn[0] : W0.ZY[0], zyjp = jj == 0 ? W0.ZY[1] : R0.ZYn[1];                             \
+      const double zy_m = Wm.ZY4[jj + 1], zy_p = Wp.ZY4[jj + 1], zx_m = Wm.ZX[jj], zx_p = Wp.ZX[jj];                         \
+      const double zyjm = W0.ZY4[jj], zyjp = W0.ZY4[jj + 2];                                                                \
       const double zxim = R0.ZXm[jj], zxip = R0.ZXp[jj];                                                                    \
       const double a4o = R0.A4[jj], a4jp = R0.A4[jj + 1], a7o = R0.A7[jj], a7ip = R0.A7p[jj];                                \
       const double a2_0 = W0.A2[jj], a2_p = Wp.A2[jj];                                                                      \

@@ -273,6 +273,22 @@ __global__ void k_slopes_js(GeoView G, LevView L) {
   }
 }
 
+// interface depths zw in the JS-like layout (nz+1 rows per plane) and the 2-D factors of slots 4 and 7, for the colour pass that
+// rebuilds the interior rows of those slots instead of streaming them (mg_define_matrix.f90:532-534, 549-551):
+//   cA(4,k,j,i) = ( qrt*(zw(k+1,j,i)-zw(k,j,i)+zw(k+1,j-1,i)-zw(k,j-1,i)) * (dx(j,i)+dx(j-1,i)) ) / ( hlf*(dy(j,i)+dy(j-1,i)) )
+//   cA(7,k,j,i) = ( qrt*(zw(k+1,j,i)-zw(k,j,i)+zw(k+1,j,i-1)-zw(k,j,i-1)) * (dy(j,i)+dy(j,i-1)) ) / ( hlf*(dx(j,i)+dx(j,i-1)) )
+__global__ void k_zw_js(GeoView G, LevView L) {
+  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  const double hlf = 0.5;
+  const long long o = (long long)i * L.planew + jpos(L, j);
+  for (int k = 1; k <= nz + 1; k++) L.zw[o + (long long)(k - 1) * L.RS] = ZW(k, j, i);
+  const long long o2 = (long long)i * L.RS + jpos(L, j);
+  L.m4[o2] = j >= 1 ? DX(j, i) + DX(j - 1, i) : 0.0;
+  L.d4[o2] = j >= 1 ? hlf * (DY(j, i) + DY(j - 1, i)) : 1.0;
+  L.m7[o2] = i >= 1 ? DY(j, i) + DY(j, i - 1) : 0.0;
+  L.d7[o2] = i >= 1 ? hlf * (DX(j, i) + DX(j, i - 1)) : 1.0;
+}
+
 // tridiagonal pivots of every interior column (mg_relax.f90:322-327): bet(1)=1/d(1);
 // gam(k)=dd(k-1)*bet ; bet(k)=1/(d(k)-dd(k-1)*gam(k)) with d=cA(1,:), dd(k-1)=cA(2,k)
 __global__ void k_pivots(LevView L) {
@@ -322,5 +338,6 @@ void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
   }
 }
 void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
+void mgxs_zw_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_zw_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
 }
