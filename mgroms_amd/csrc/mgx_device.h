@@ -31,3 +31,30 @@ __device__ __forceinline__ void mirror_store(const LevView &L, double *__restric
 }
 
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
+
+// ---- switches and helpers shared by the smoother translation units ---------------------------------------------------
+// MGX_PV: the matrix-free colour pass rebuilds the diagonal and the tridiagonal pivots in the kernel instead of streaming
+// `bet` from HBM (relax_col_mf); -DMGX_NO_PV keeps the stored pivots for A/B measurements (same bits either way).
+#ifdef MGX_NO_PV
+#define MGX_PV 0
+#else
+#define MGX_PV 1
+#endif
+#ifndef MGX_GL
+#define MGX_GL 1
+#endif
+// The j-1 and j+1 neighbours of a column sit side by side in the other half-row (jp = jm + 1): ONE 16-byte load per lane fetches
+// both, instead of two 8-byte loads whose wave-wide footprints overlap by 63/64 (half the wave-level requests for these streams;
+// 8-byte alignment only: gfx950 global loads do not need natural alignment)
+#ifndef MGX_PAIR
+#define MGX_PAIR 1
+#endif
+#ifndef MGX_ZW
+#define MGX_ZW 1
+#endif
+#if MGX_PAIR
+#define LD_PAIR(ptr, A, B) { double2 t2_; __builtin_memcpy(&t2_, (ptr), 16); A = t2_.x; B = t2_.y; }
+#else
+#define LD_PAIR(ptr, A, B) { A = (ptr)[0]; B = (ptr)[1]; }
+#endif
+
