@@ -1,0 +1,138 @@
+// Coarsest-level solve, relax(nlevs, ns_coarsest = 40) of mg_solvers.f90:117,144, as ONE wave.
+//
+// 40 sweeps of a 16x16x2 grid are 160 dependent colour passes.  k_relax_reg (mgx_relax.hip) runs them in one workgroup with a
+// thread per column: in a four-colour pass a quarter of the threads work, three waves idle at the barrier, 0.56 us per pass.
+// Here a level of <= 256 columns is ONE wave: every lane owns a 2x2 block of columns, i.e. one column of each of the four
+// colours (two of each red-black colour), so all 64 lanes work in every pass and the passes are separated by a
+// single-wave barrier only.  Everything that does not change between passes -- b, the own slots and pivots, the slots of the
+// j+1 / i+1 neighbours, gam -- sits in registers (4 columns x NZ rows x 16 values); p lives in LDS with its mirrored halo.
+// Same expressions in the same order as relax_col_nz / k_relax_reg: bit-identical.
+#include <cstdlib>
+
+#include "mgx_device.h"
+
+template <int NZ, bool REAL>
+__global__ __launch_bounds__(64, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph) {
+  extern __shared__ double ldsw[];
+  const int nx = G.nx, ny = G.ny, W = ny + 2, PL = (nx + 2) * W;  // P[k][i][j]
+  double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
+  const int lane = threadIdx.x;
+#define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
+  for (int t = lane; t < NZ * PL; t += WAVE) {
+    const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W;
+    P[t] = G.p[GI(k0, j, i)];
+  }
+  const int nbj = ny >> 1;
+  const bool mine = lane < (nx >> 1) * nbj;
+  const int bi = lane / nbj, bj = lane - bi * nbj;
+  // column q of the lane: (i,j) = (2 bi + 1 + (q >> 1), 2 bj + 1 + (q & 1)); q = 0..3 are the four colours in the reference's order
+  double ob[4][NZ], a2[4][NZ], a3[4][NZ], a4[4][NZ], a5[4][NZ], a6[4][NZ], a7[4][NZ], a8[4][NZ], bet[4][NZ], g[4][NZ];
+  double r3[4][NZ], r4[4][NZ], r5[4][NZ], r6[4][NZ], r7[4][NZ], r8[4][NZ], e2[4], e4[4];
+  if (mine) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = 2 * bi + 1 + (q >> 1), j = 2 * bj + 1 + (q & 1);
+#pragma unroll
+      for (int k = 0; k < NZ; k++) {
+        const long long c = GI(k, j, i), cj = GI(k, j + 1, i), ci = GI(k, j, i + 1);
+        ob[q][k] = G.b[c]; a2[q][k] = G.cA[1][c]; a3[q][k] = G.cA[2][c]; a4[q][k] = G.cA[3][c]; a5[q][k] = G.cA[4][c];
+        a6[q][k] = G.cA[5][c]; a7[q][k] = G.cA[6][c]; a8[q][k] = G.cA[7][c]; bet[q][k] = G.bet[c];
+        r3[q][k] = G.cA[2][cj]; r4[q][k] = G.cA[3][cj]; r5[q][k] = G.cA[4][cj];
+        r6[q][k] = G.cA[5][ci]; r7[q][k] = G.cA[6][ci]; r8[q][k] = G.cA[7][ci];
+      }
+      e2[q] = e4[q] = 0.0;
+      if (REAL) { e2[q] = G.cA[4][GI(0, j - 1, i + 1)]; e4[q] = G.cA[7][GI(0, j + 1, i + 1)]; }
+      g[q][0] = 0.0;
+#pragma unroll
+      for (int k = 1; k < NZ; k++) g[q][k] = a2[q][k] * bet[q][k - 1];  // gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325)
+    }
+  }
+  __syncthreads();
+  // one column solve; Q1 = where the k=1 horizontal diagonals are read (the snapshot for red-black, p itself for four-colour)
+#define COLUMN(q)                                                                                                          \
+  {                                                                                                                         \
+    const int i = 2 * bi + 1 + ((q) >> 1), j = 2 * bj + 1 + ((q) & 1);                                                       \
+    const bool mS = ph.S && j == 1, mN = ph.N && j == ny, mW = ph.W && i == 1, mE = ph.E && i == nx;                         \
+    double x[NZ];                                                                                                           \
+    double d1 = 0, d2 = 0, d3 = 0, d4 = 0;                                                                                  \
+    if (REAL) { d1 = Q1[(i - 1) * W + j + 1]; d2 = Q1[(i + 1) * W + j - 1]; d3 = Q1[(i - 1) * W + j - 1]; d4 = Q1[(i + 1) * W + j + 1]; } \
+    double pjm[NZ], pjp[NZ], pim[NZ], pip[NZ];                                                                              \
+    _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
+      const int o = k * PL + i * W + j;                                                                                     \
+      pjm[k] = P[o - 1]; pjp[k] = P[o + 1]; pim[k] = P[o - W]; pip[k] = P[o + W];                                           \
+    }                                                                                                                       \
+    double xv = 0.0;                                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
+      double rhs;                                                                                                           \
+      if (k == 0) {                                                                                                         \
+        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k] - r5[q][k + 1] * pjp[k + 1]          \
+                       - a6[q][k] * pim[k + 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k] - r8[q][k + 1] * pip[k + 1];          \
+        if (REAL) rhs = rhs - a5[q][0] * d1 - e2[q] * d2 - a8[q][0] * d3 - e4[q] * d4;                                      \
+        xv = rhs * bet[q][k];                                                                                               \
+      } else if (k < NZ - 1) {                                                                                              \
+        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - r3[q][k - 1] * pjp[k - 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k]          \
+                       - a5[q][k] * pjm[k - 1] - r5[q][k + 1] * pjp[k + 1]                                                  \
+                       - a6[q][k] * pim[k + 1] - r6[q][k - 1] * pip[k - 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k]          \
+                       - a8[q][k] * pim[k - 1] - r8[q][k + 1] * pip[k + 1];                                                 \
+        xv = (rhs - a2[q][k] * xv) * bet[q][k];                                                                             \
+      } else {                                                                                                              \
+        rhs = ob[q][k] - r3[q][k - 1] * pjp[k - 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k] - a5[q][k] * pjm[k - 1]          \
+                       - r6[q][k - 1] * pip[k - 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k] - a8[q][k] * pim[k - 1];          \
+        xv = (rhs - a2[q][k] * xv) * bet[q][k];                                                                             \
+      }                                                                                                                     \
+      x[k] = xv;                                                                                                            \
+    }                                                                                                                       \
+    _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - g[q][k + 1] * x[k + 1];                               \
+    _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
+      const int o = k * PL;                                                                                                 \
+      const double v = x[k];                                                                                                \
+      P[o + i * W + j] = v;                                                                                                 \
+      if (mS) P[o + i * W] = v;                                                                                             \
+      if (mN) P[o + i * W + ny + 1] = v;                                                                                    \
+      if (mW) { P[o + j] = v; if (mS) P[o] = v; if (mN) P[o + ny + 1] = v; }                                                \
+      if (mE) { P[o + (nx + 1) * W + j] = v; if (mS) P[o + (nx + 1) * W] = v; if (mN) P[o + (nx + 1) * W + ny + 1] = v; }   \
+    }                                                                                                                       \
+  }
+  for (int it = 0; it < nsweeps; it++) {
+    if (method == 2) {  // four colours (mg_relax.f90:212-230): (i odd,j odd), (i odd,j even), (i even,j odd), (i even,j even)
+      const double *__restrict__ Q1 = P;
+      if (mine) COLUMN(0)
+      __syncthreads();
+      if (mine) COLUMN(1)
+      __syncthreads();
+      if (mine) COLUMN(2)
+      __syncthreads();
+      if (mine) COLUMN(3)
+      __syncthreads();
+    } else {  // red-black (mg_relax.f90:170-186), parallel semantics: same-colour k=1 diagonals from the snapshot taken before the pass
+      const double *__restrict__ Q1 = REAL ? P1 : P;
+      if (REAL) { for (int t = lane; t < PL; t += WAVE) P1[t] = P[t]; __syncthreads(); }
+      if (mine) { COLUMN(0) COLUMN(3) }   // rb = 1: j = 1+mod(i+1,2): (i odd, j odd) and (i even, j even)
+      __syncthreads();
+      if (REAL) { for (int t = lane; t < PL; t += WAVE) P1[t] = P[t]; __syncthreads(); }
+      if (mine) { COLUMN(1) COLUMN(2) }   // rb = 2
+      __syncthreads();
+    }
+  }
+#undef COLUMN
+  for (int t = lane; t < NZ * PL; t += WAVE) {
+    const int k0 = t / PL, r = t - k0 * PL, ii = r / W, jj = r - ii * W;
+    G.p[GI(k0, jj, ii)] = P[t];
+  }
+#undef GI
+}
+
+extern "C" {
+
+// returns 1 when launched: a closed level of <= 256 columns with nz = 2 (the coarsest grid of every BASELINE configuration)
+int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
+  static const bool off = getenv("MGX_NO_WAVE") != nullptr;
+  if (off || L->nz != 2 || method == 0 || (exact && method == 1 && real)) return 0;
+  if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || (L->nx / 2) * (L->ny / 2) > WAVE) return 0;
+  const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
+  if (real) hipLaunchKernelGGL((k_relax_wave<2, true>), dim3(1), dim3(WAVE), bytes, st, *L, nsweeps, method, ph);
+  else hipLaunchKernelGGL((k_relax_wave<2, false>), dim3(1), dim3(WAVE), bytes, st, *L, nsweeps, method, ph);
+  return 1;
+}
+
+}  // extern "C"
