@@ -242,7 +242,9 @@ def main():
     # (profiles/r02_pmc_traffic.json, made by scripts/pmc_summary.py) and labelled as such
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>"
+    # the level-1 colour pass of the headline workload (nz = 64, level too large for the Infinity Cache); other --size values run
+    # other kernels (k_relax_ks for nz <= 32 when a colour has <= 512 waves, k_relax_tall for nz = 128)
+    kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>" if nz == 64 else f"level-1 colour pass, nz={nz}"
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
