@@ -58,7 +58,7 @@ void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
 void mgxs_define_matrix(hipStream_t, const GeoView *, int lev1, int phase);
 void mgxs_pivots(hipStream_t, const LevView *);
 void mgxs_slopes_js(hipStream_t, const GeoView *, const LevView *);
-void mgxs_zw_js(hipStream_t, const GeoView *, const LevView *);
+void mgxs_zw_js(hipStream_t, const GeoView *, const LevView *, double, double, double);
 void mgxm_ref2model(hipStream_t, const double *, double *, int rows, int nh, int nx, int ny);
 void mgxm_ref2model_2d(hipStream_t, const double *, double *, int nx, int ny);
 void mgxm_js_model(hipStream_t, const LevView *, double *js, double *md, int dir);
@@ -103,7 +103,7 @@ struct Level {
   unsigned long long p2p_gseq = 0;
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
-  double *zw_store = nullptr, *f2d_store[4] = {nullptr, nullptr, nullptr, nullptr};  // zw (JS, nz+1 rows) and m4,d4,m7,d7 (LevView)
+  double *f2d_store[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *tab_store[2] = {nullptr, nullptr};  // m4,d4,m7,d7,h2,hi2,ze2 and cffw,csw (LevView)
 };
 
 struct State {
@@ -738,9 +738,10 @@ int define_matrices() {
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
-    L.v.zw = L.zw_store; L.v.m4 = L.f2d_store[0]; L.v.d4 = L.f2d_store[1]; L.v.m7 = L.f2d_store[2]; L.v.d7 = L.f2d_store[3];
-    mgxs_zw_js(S.stream, &L.g, &L.v); S.n_launch++;
-    if (S.no_mf || S.par.bmask) { L.v.zy = L.v.zx = nullptr; L.v.zw = L.v.m4 = L.v.d4 = L.v.m7 = L.v.d7 = nullptr; }  // masked coefficients are not rebuilt from the slopes
+    L.v.m4 = L.f2d_store[0]; L.v.d4 = L.f2d_store[1]; L.v.m7 = L.f2d_store[2]; L.v.d7 = L.f2d_store[3];
+    L.v.h2 = L.f2d_store[4]; L.v.hi2 = L.f2d_store[5]; L.v.ze2 = L.f2d_store[6]; L.v.cffw = L.tab_store[0]; L.v.csw = L.tab_store[1];
+    mgxs_zw_js(S.stream, &L.g, &L.v, S.hlim, S.theta_b, S.theta_s); S.n_launch += 2;
+    if (S.no_mf || S.par.bmask) { L.v.zy = L.v.zx = nullptr; L.v.m4 = nullptr; }  // masked coefficients are not rebuilt from the slopes
   }
   CHK(sync_stream());
   S.have_matrix = true;
@@ -1058,10 +1059,9 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.p1b, (size_t)(L.nx + 2) * L.v.RS)); L.v.p1w = nullptr;
     CHK(dmalloc(&L.zy_store, L.n3js)); CHK(dmalloc(&L.zx_store, L.n3js));
     L.v.zy = L.v.zx = nullptr;
-    L.v.planew = (long long)(L.nz + 1) * L.v.RS;
-    CHK(dmalloc(&L.zw_store, (size_t)(L.nx + 2) * L.v.planew));
-    for (int q = 0; q < 4; q++) CHK(dmalloc(&L.f2d_store[q], (size_t)(L.nx + 2) * L.v.RS));
-    L.v.zw = L.v.m4 = L.v.d4 = L.v.m7 = L.v.d7 = nullptr;
+    for (int q = 0; q < 7; q++) CHK(dmalloc(&L.f2d_store[q], (size_t)(L.nx + 2) * L.v.RS));
+    for (int q = 0; q < 2; q++) CHK(dmalloc(&L.tab_store[q], (size_t)L.nz + 1));
+    L.v.m4 = L.v.d4 = L.v.m7 = L.v.d7 = L.v.h2 = L.v.hi2 = L.v.ze2 = nullptr; L.v.cffw = L.v.csw = nullptr;
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
     CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));
@@ -1373,7 +1373,7 @@ int mgx_set_field(int lev, int field, const double *host) {
     for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 0);
     mgxs_pivots(S.stream, &L.v);
     L.v.zy = L.v.zx = nullptr;  // a user-supplied matrix is used as stored
-    L.v.zw = L.v.m4 = L.v.d4 = L.v.m7 = L.v.d7 = nullptr;
+    L.v.m4 = nullptr;
     S.have_matrix = true;
   } else if (!field_ptr(L, field, &a, &n)) {
     HIPCHK(hipMemcpyAsync(a, host, n * sizeof(double), hipMemcpyHostToDevice, S.stream));

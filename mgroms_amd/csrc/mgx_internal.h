@@ -19,11 +19,13 @@ struct LevView {
   double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
   double *p1w;      // when set: the colour pass also writes its new k=1 values here (= the snapshot of the NEXT sweep)
   double *zy, *zx;  // slopes ZY, ZX (JS layout) for the matrix-free cross terms; nullptr = use the stored slots
-  // interior rows of slots 4 and 7 rebuilt in the kernel (mg_define_matrix.f90:532-534,549-551) from the interface depths:
-  // zw in a JS-like layout with nz+1 rows per plane (planew = (nz+1)*RS) and four 2-D factor arrays, one row of RS per plane:
-  // m4 = dx(j,i)+dx(j-1,i), d4 = hlf*(dy(j,i)+dy(j-1,i)), m7 = dy(j,i)+dy(j,i-1), d7 = hlf*(dx(j,i)+dx(j,i-1)).  nullptr = stored slots.
-  double *zw, *m4, *d4, *m7, *d7;
-  long long planew;
+  // Interior rows of slots 4 and 7 rebuilt in the kernel (mg_define_matrix.f90:532-534,549-551) from the interface depths zw, and zw
+  // itself from its generating formula (mg_zr_zw.f90:140-145): zw(k,j,i) = z0*h*hinv + zeta*(1.+z0*hinv), z0 = cffw(k) + csw(k)*h --
+  // two 1-D tables of nz+1 entries (cffw = hlim*sc_w, csw = Cs_w) and three 2-D fields (h, hinv = 1/(h+hlim), zeta), no 3-D array.
+  // 2-D arrays: one row of RS per plane i, JS j-order.  m4 = dx(j,i)+dx(j-1,i), d4 = hlf*(dy(j,i)+dy(j-1,i)),
+  // m7 = dy(j,i)+dy(j,i-1), d7 = hlf*(dx(j,i)+dx(j,i-1)).  nullptr = stored slots.
+  double *m4, *d4, *m7, *d7, *h2, *hi2, *ze2;
+  const double *cffw, *csw;
 };
 
 __host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }

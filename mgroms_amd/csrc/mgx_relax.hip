@@ -247,10 +247,13 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 // (one wave per SIMD: 128 KB of the CU's 160 KB) frees 128 registers, and the backward sweep's reads are independent of its
 // dependency chain.
 // ZW: the interior rows of slots 4 and 7 (own and of the j+1 / i+1 neighbour: four streams) are rebuilt from the interface depths
-// zw of the column and of its four face neighbours (three streams: own, the j-1/j+1 pair in one 16-byte load, i-1 and i+1 shared
-// with the neighbouring planes' passes) with the reference's expressions (mg_define_matrix.f90:532-534,549-551; the 2-D factors come
-// precomputed, k_zw_js): bit-identical values, one stream less, four more fp64 divisions per row under the loads.  Rows 1 and nz
-// have other formulas (:361-372,:577-590): they read the stored slots.
+// zw of the column and of its four face neighbours with the reference's expressions (mg_define_matrix.f90:532-534,549-551; the 2-D
+// factors come precomputed, k_zw_js), and those depths are not streamed either: the sigma coordinate generates them,
+// zw(k,j,i) = z0*h*hinv + zeta*(1.+z0*hinv) with z0 = cffw(k) + csw(k)*h (mg_zr_zw.f90:140-145), from three 2-D values per column
+// (h, hinv, zeta: loaded once) and two table entries per row that are the same for every lane (scalar loads).  Same expressions,
+// bit-identical values (the halo columns too: h and zeta carry the same mirror / exchange rules as zw), FOUR streams less, at seven
+// flops per depth and four fp64 divisions per row under the loads.  Rows 1 and nz of slots 4 / 7 have other formulas
+// (:361-372,:577-590): they read the stored slots.
 template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false, bool ZW = false>
 __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph, double *__restrict__ gl = nullptr) {
   int c, jm, jp;
@@ -270,9 +273,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
   double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
   double x[NZ], g[GL ? 1 : NZ];
-  double w_o[RO], w_jm[RO], w_jp[RO], w_im[RO], w_ip[RO];  // ZW: zw of the column and of its face neighbours, rows k .. k+1+D
-  const double *__restrict__ zw = L.zw;
-  const long long wo = (long long)i * L.planew, wom = wo - L.planew, wop = wo + L.planew;
+  double zw0[5], zw1[5];  // ZW: generated zw of the column and of its j-1, j+1, i-1, i+1 neighbours, rows k and k+1
   const int lane = threadIdx.x;
 #define G_PUT(kk, v) { if (GL) gl[((kk)-1) * WAVE + lane] = (v); else g[GL ? 0 : (kk)-1] = (v); }
 
@@ -284,14 +285,12 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     LD_PAIR(zy + o + ro_ + jm, r_zyjm[s_], r_zyjp[s_])                            \
     r_zxim[s_] = *(zx + om + ro_ + c); r_zxip[s_] = *(zx + op + ro_ + c); \
     if (!ZW) { r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c); }  \
-    else if ((q) >= 2) { LD_PAIR(zw + wo + ro_ + jm, w_jm[s_], w_jp[s_]) w_im[s_] = zw[wom + ro_ + c]; w_ip[s_] = zw[wop + ro_ + c]; } \
   }
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
     o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); \
     if (!ZW) { o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); } \
-    else if ((q) >= 2) w_o[s_] = ld_stream<ST>(zw + wo + (long long)((q)-1) * RS + c); \
     if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
     o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
@@ -299,6 +298,8 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   double dg1 = 0, dgn = 0;
   if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
   // ZW: stored slots 4 and 7 of the first and the last row, and the per-column factors of the interior formula
+  double hh[5], hv[5], hz[5];  // h, hinv, zeta of the five columns
+  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw;
   double a4_1 = 0, a4j_1 = 0, a7_1 = 0, a7i_1 = 0, a4_n = 0, a4j_n = 0, a7_n = 0, a7i_n = 0, m4c = 0, m4p = 0, d4c = 1, d4p = 1, m7c = 0, m7p = 0, d7c = 1, d7p = 1;
   if (ZW) {
     const long long rn = (long long)(NZ - 1) * RS;
@@ -307,7 +308,12 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     const long long q2 = (long long)i * RS;
     m4c = L.m4[q2 + c]; m4p = L.m4[q2 + jp]; d4c = L.d4[q2 + c]; d4p = L.d4[q2 + jp];
     m7c = L.m7[q2 + c]; m7p = L.m7[q2 + RS + c]; d7c = L.d7[q2 + c]; d7p = L.d7[q2 + RS + c];
+    const long long cq[5] = {q2 + c, q2 + jm, q2 + jp, q2 - RS + c, q2 + RS + c};  // the column, j-1, j+1, i-1, i+1
+#pragma unroll
+    for (int q = 0; q < 5; q++) { hh[q] = L.h2[cq[q]]; hv[q] = L.hi2[cq[q]]; hz[q] = L.ze2[cq[q]]; }
   }
+  // zw(kk, column q) by its generating formula (mg_zr_zw.f90:140-145)
+#define ZW_GEN(kk, q) ({ const double z0_ = cffw[(kk)-1] + csw[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
     const double *__restrict__ q1 = SNAP ? L.p1 : p;
@@ -345,12 +351,19 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     else if (k == 1) { a4o = a4_1; a4jp = a4j_1; a7o = a7_1; a7ip = a7i_1; }
     else if (k == NZ) { a4o = a4_n; a4jp = a4j_n; a7o = a7_n; a7ip = a7i_n; }
     else {
-      const int sp = (k + 1) % RO, np = (k + 1) % RN;
-      const double wo0 = w_o[s], wop1 = w_o[sp];
-      a4o = (qrt * (wop1 - wo0 + w_jm[np] - w_jm[n]) * m4c) / d4c;
-      a4jp = (qrt * (w_jp[np] - w_jp[n] + wop1 - wo0) * m4p) / d4p;
-      a7o = (qrt * (wop1 - wo0 + w_im[np] - w_im[n]) * m7c) / d7c;
-      a7ip = (qrt * (w_ip[np] - w_ip[n] + wop1 - wo0) * m7p) / d7p;
+      if (k == 2) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) zw0[q] = ZW_GEN(2, q);
+      }
+#pragma unroll
+      for (int q = 0; q < 5; q++) zw1[q] = ZW_GEN(k + 1, q);
+      const double wo0 = zw0[0], wop1 = zw1[0];
+      a4o = (qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c) / d4c;
+      a4jp = (qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p) / d4p;
+      a7o = (qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c) / d7c;
+      a7ip = (qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p) / d7p;
+#pragma unroll
+      for (int q = 0; q < 5; q++) zw0[q] = zw1[q];
     }
     double betk;
     if (MGX_PV) {
@@ -425,6 +438,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   }
 #undef NB_LOAD
 #undef OW_LOAD
+#undef ZW_GEN
 }
 
 template <int NZ, bool REAL, bool SNAP, int D, bool MF, bool ST>

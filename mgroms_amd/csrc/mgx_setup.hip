@@ -273,20 +273,36 @@ __global__ void k_slopes_js(GeoView G, LevView L) {
   }
 }
 
-// interface depths zw in the JS-like layout (nz+1 rows per plane) and the 2-D factors of slots 4 and 7, for the colour pass that
-// rebuilds the interior rows of those slots instead of streaming them (mg_define_matrix.f90:532-534, 549-551):
+// What the colour pass needs to rebuild the interior rows of slots 4 and 7 instead of streaming them (mg_define_matrix.f90:532-534,
+// 549-551):
 //   cA(4,k,j,i) = ( qrt*(zw(k+1,j,i)-zw(k,j,i)+zw(k+1,j-1,i)-zw(k,j-1,i)) * (dx(j,i)+dx(j-1,i)) ) / ( hlf*(dy(j,i)+dy(j-1,i)) )
 //   cA(7,k,j,i) = ( qrt*(zw(k+1,j,i)-zw(k,j,i)+zw(k+1,j,i-1)-zw(k,j,i-1)) * (dy(j,i)+dy(j,i-1)) ) / ( hlf*(dx(j,i)+dx(j,i-1)) )
-__global__ void k_zw_js(GeoView G, LevView L) {
+// with zw regenerated from h, hinv, zeta and the two sigma tables (mg_zr_zw.f90:104-145): the 2-D factors and fields, JS j-order.
+__global__ void k_zw_js(GeoView G, LevView L, double hlim) {
   COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
-  const double hlf = 0.5;
-  const long long o = (long long)i * L.planew + jpos(L, j);
-  for (int k = 1; k <= nz + 1; k++) L.zw[o + (long long)(k - 1) * L.RS] = ZW(k, j, i);
+  const double hlf = 0.5, one = 1.0;
   const long long o2 = (long long)i * L.RS + jpos(L, j);
   L.m4[o2] = j >= 1 ? DX(j, i) + DX(j - 1, i) : 0.0;
   L.d4[o2] = j >= 1 ? hlf * (DY(j, i) + DY(j - 1, i)) : 1.0;
   L.m7[o2] = i >= 1 ? DY(j, i) + DY(j, i - 1) : 0.0;
   L.d7[o2] = i >= 1 ? hlf * (DX(j, i) + DX(j, i - 1)) : 1.0;
+  const double h = A2(G.h, j, i);
+  L.h2[o2] = h;
+  L.hi2[o2] = one / (h + hlim);   // hinv of mg_zr_zw.f90:106, the same expression as k_zr_zw
+  L.ze2[o2] = A2(G.zeta, j, i);
+}
+// sigma tables of the w-points, k = 1..nz+1: cffw(k) = hlim*sc_w, csw(k) = Cs_w (mg_zr_zw.f90:124-141), same expressions as k_zr_zw
+__global__ void k_sigma_tables(int nz, double hlim, double theta_b, double theta_s, double *cffw, double *csw) {
+  const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nz + 1) return;
+  const double one = 1.0, nul = 0.0;
+  const double cff = one / (double)nz;
+  double cswf, cs_w;
+  const double sc_w = cff * (double)(k - 1 - nz);
+  if (theta_s > nul) cswf = (one - cosh(theta_s * sc_w)) / (cosh(theta_s) - one); else cswf = -(sc_w * sc_w);
+  if (theta_b > nul) cs_w = (exp(theta_b * cswf) - one) / (one - exp(-theta_b)); else cs_w = cswf;
+  cffw[k - 1] = hlim * sc_w;
+  csw[k - 1] = cs_w;
 }
 
 // tridiagonal pivots of every interior column (mg_relax.f90:322-327): bet(1)=1/d(1);
@@ -338,6 +354,9 @@ void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
   }
 }
 void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
-void mgxs_zw_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_zw_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
+void mgxs_zw_js(hipStream_t st, const GeoView *G, const LevView *L, double hlim, double theta_b, double theta_s) {
+  hipLaunchKernelGGL(k_zw_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L, hlim);
+  hipLaunchKernelGGL(k_sigma_tables, dim3((G->nz + 1 + 63) / 64), dim3(64), 0, st, G->nz, hlim, theta_b, theta_s, (double *)L->cffw, (double *)L->csw);
+}
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
 }
