@@ -462,11 +462,11 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
   constexpr bool GL = MF && NZ == 64 && MGX_GL;  // keep in step with launch_relax_nz_d
-  constexpr bool ZW = MF && NZ == 64 && MGX_ZW;
+  constexpr bool ZW = MF && NZ >= 32 && MGX_ZW;
   if (GL) {
     extern __shared__ double g_lds[];  // blockDim.y waves x NZ rows x 64 lanes
     relax_col_mf<NZ, REAL, SNAP, D, ST, GL, ZW>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
-  } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST>(L, i, jh, jodd, ph);
+  } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST, false, ZW>(L, i, jh, jodd, ph);
   else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }
 

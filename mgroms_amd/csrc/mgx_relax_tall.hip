@@ -1,6 +1,7 @@
 // z-line smoother for tall columns (nz = 128, BASELINE config 5): one colour pass, matrix-free cross terms, the lower 64 rows'
-// forward values in LDS.  mg_relax.f90:237-305 + :308-334.  Its own translation unit: x and gam of 64 rows stay in registers here,
-// and neither the 16-byte pair loads nor the zw-form of slots 4 / 7 of mgx_relax.hip fit next to them (0.8 KB/lane of scratch).
+// forward values in LDS.  mg_relax.f90:237-305 + :308-334.  Its own translation unit: x and gam of 64 rows stay in registers here
+// (500 of 512), it needs a larger `#pragma unroll` budget than the others (Makefile), and the 16-byte pair loads of mgx_relax.hip
+// do not fit next to them (0.8 KB/lane of scratch); slots 4 / 7 from regenerated zw do.
 #include <cstdlib>
 
 #include "mgx_device.h"
@@ -30,6 +31,9 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
   double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
   constexpr int UP = NZ - LOW;
   double x[UP], g[UP];
+  constexpr bool ZW = MGX_ZW;  // slots 4 and 7 of the interior rows from regenerated interface depths, see relax_col_mf (mgx_relax.hip)
+  double zw0[5], zw1[5], hh[5], hv[5], hz[5];
+  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw;
 
 #define NB_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
@@ -38,17 +42,31 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     r_pjp[s_] = p[o + ro_ + jp]; r_pip[s_] = p[op + ro_ + c];                    \
     r_zyjm[s_] = *(zy + o + ro_ + jm); r_zyjp[s_] = *(zy + o + ro_ + jp); \
     r_zxim[s_] = *(zx + om + ro_ + c); r_zxip[s_] = *(zx + op + ro_ + c); \
-    r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c);      \
+    if (!ZW) { r_a4[s_] = *(a4 + o + ro_ + jp); r_a7[s_] = *(a7 + op + ro_ + c); }      \
   }
 #define OW_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
     const long long ko_ = o + (long long)((q)-1) * RS + c; const int s_ = (q) % RO; \
-    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); \
+    o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); \
+    if (!ZW) { o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); } \
     if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
     o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
   }
   double dg1 = 0, dgn = 0;
   if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
+  double a4_1 = 0, a4j_1 = 0, a7_1 = 0, a7i_1 = 0, a4_n = 0, a4j_n = 0, a7_n = 0, a7i_n = 0, m4c = 0, m4p = 0, d4c = 1, d4p = 1, m7c = 0, m7p = 0, d7c = 1, d7p = 1;
+  if (ZW) {
+    const long long rn = (long long)(NZ - 1) * RS;
+    a4_1 = a4[o + c]; a4j_1 = a4[o + jp]; a7_1 = a7[o + c]; a7i_1 = a7[op + c];
+    a4_n = a4[o + rn + c]; a4j_n = a4[o + rn + jp]; a7_n = a7[o + rn + c]; a7i_n = a7[op + rn + c];
+    const long long q2 = (long long)i * RS;
+    m4c = L.m4[q2 + c]; m4p = L.m4[q2 + jp]; d4c = L.d4[q2 + c]; d4p = L.d4[q2 + jp];
+    m7c = L.m7[q2 + c]; m7p = L.m7[q2 + RS + c]; d7c = L.d7[q2 + c]; d7p = L.d7[q2 + RS + c];
+    const long long cq[5] = {q2 + c, q2 + jm, q2 + jp, q2 - RS + c, q2 + RS + c};
+#pragma unroll
+    for (int q = 0; q < 5; q++) { hh[q] = L.h2[cq[q]]; hv[q] = L.hi2[cq[q]]; hz[q] = L.ze2[cq[q]]; }
+  }
+#define ZW_GEN(kk, q) ({ const double z0_ = cffw[(kk)-1] + csw[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
     const double *__restrict__ q1 = SNAP ? L.p1 : p;
@@ -80,12 +98,26 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n]; \
     const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p); \
     const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p); \
+    double a4o, a4jp, a7o, a7ip; \
+    if (!ZW) { a4o = o_a4[s]; a4jp = r_a4[n]; a7o = o_a7[s]; a7ip = r_a7[n]; } \
+    else if (k == 1) { a4o = a4_1; a4jp = a4j_1; a7o = a7_1; a7ip = a7i_1; } \
+    else if (k == NZ) { a4o = a4_n; a4jp = a4j_n; a7o = a7_n; a7ip = a7i_n; } \
+    else { \
+      if (k == 2) { _Pragma("unroll") for (int q = 0; q < 5; q++) zw0[q] = ZW_GEN(2, q); } \
+      _Pragma("unroll") for (int q = 0; q < 5; q++) zw1[q] = ZW_GEN(k + 1, q); \
+      const double wo0 = zw0[0], wop1 = zw1[0]; \
+      a4o = (qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c) / d4c; \
+      a4jp = (qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p) / d4p; \
+      a7o = (qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c) / d7c; \
+      a7ip = (qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p) / d7p; \
+      _Pragma("unroll") for (int q = 0; q < 5; q++) zw0[q] = zw1[q]; \
+    } \
     double betk; \
     if (MGX_PV) { /* pivots in the kernel, see relax_col_mf */ \
       double dk; \
       if (k == 1) dk = dg1; \
       else if (k == NZ) dk = dgn; \
-      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - o_a4[s] - r_a4[n] - o_a7[s] - r_a7[n] - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m; \
+      else dk = -o_a2[s] - o_a2[(k + 1) % RO] - a4o - a4jp - a7o - a7ip - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m; \
       if (k == 1) betk = 1.0 / dk; \
       else { const double gk = o_a2[s] * betp; if (k > LOW + 1) g[k - LOW - 1] = gk; betk = 1.0 / (dk - o_a2[s] * gk); } \
     } else { \
@@ -95,19 +127,19 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     betp = betk; \
     double rhs; \
     if (k == 1) { \
-      rhs = o_b[s] - c3 * pjm_p - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5m * pjp_p \
-                   - c6 * pim_p - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8m * pip_p; \
+      rhs = o_b[s] - c3 * pjm_p - a4o * pjm_0 - a4jp * pjp_0 - c5m * pjp_p \
+                   - c6 * pim_p - a7o * pim_0 - a7ip * pip_0 - c8m * pip_p; \
       if (REAL) rhs = rhs - e1 * d1 - e2 * d2 - e3 * d3 - e4 * d4; \
       xv = rhs * betk; \
     } else if (k < NZ) { \
-      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 \
+      rhs = o_b[s] - c3 * pjm_p - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0 \
                    - c5 * pjm_m - c5m * pjp_p \
-                   - c6 * pim_p - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 \
+                   - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0 \
                    - c8 * pim_m - c8m * pip_p; \
       xv = (rhs - o_a2[s] * xv) * betk; \
     } else { \
-      rhs = o_b[s] - c3m * pjp_m - o_a4[s] * pjm_0 - r_a4[n] * pjp_0 - c5 * pjm_m \
-                   - c6m * pip_m - o_a7[s] * pim_0 - r_a7[n] * pip_0 - c8 * pim_m; \
+      rhs = o_b[s] - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0 - c5 * pjm_m \
+                   - c6m * pip_m - a7o * pim_0 - a7ip * pip_0 - c8 * pim_m; \
       xv = (rhs - o_a2[s] * xv) * betk; \
     } \
     if (k > LOW) x[k - LOW - 1] = xv; else xf[(k - 1) * WAVE + lane] = xv; \
@@ -123,6 +155,7 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
 #pragma unroll
   for (int k = LOW + 1; k <= NZ; k++) FWD_ROW(k)
 #undef FWD_ROW
+#undef ZW_GEN
 #pragma unroll
   for (int k = UP - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
 
