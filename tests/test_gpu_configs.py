@@ -201,6 +201,35 @@ def test_level1_red_black_two_waves_per_block(mg, nz):
     o.close()
 
 
+@pytest.mark.parametrize("dims", [(32, 64, 64), (16, 32, 128), (64, 64, 32)])
+def test_in_kernel_coefficients_match_stored_slots_on_stretched_grids(mg, dims, monkeypatch):
+    """The level-1 smoother rebuilds the pivots, the diagonal, slots 3,5,6,8 (slopes), slots 4 / 7 and the interface depths zw
+    (sigma-coordinate formula) in registers.  With a stretched coordinate (theta_s, theta_b > 0: cosh / exp tables), a moving free
+    surface (zeta /= 0), non-uniform dx, dy and a non-zero hc, the result must equal, bit for bit, the same solve through the STORED
+    coefficients (MGX_NO_MF=1: no in-kernel reconstruction) -- device against device, so libm differences do not enter."""
+    from mgroms_amd.testcases import seamount_geometry, resting_column_state
+    nx, ny, nz = dims
+    dx, dy, zeta, h = seamount_geometry(nx, ny)
+    ii, jj = np.meshgrid(np.arange(nx + 2), np.arange(ny + 2), indexing="ij")
+    dx = dx * (1.0 + 0.2 * np.sin(0.3 * ii)); dy = dy * (1.0 + 0.1 * np.cos(0.2 * jj))
+    zeta = 0.4 * np.cos(0.25 * ii) * np.sin(0.15 * jj)
+    u, v, w = resting_column_state(nx, ny, nz)
+    out = []
+    for nomf in (False, True):
+        if nomf:
+            monkeypatch.setenv("MGX_NO_MF", "1")
+        else:
+            monkeypatch.delenv("MGX_NO_MF", raising=False)
+        mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(relax_method="FC"))
+        mg.nhydro_matrices(dx, dy, zeta, h, None, 250.0, 0.4, 6.0)
+        mg.nhydro.compute_rhs(u, v, w)
+        n, hist = mg.solve_p(1e-12, 3)
+        out.append((hist.copy(), mg.grid(1).p))
+    monkeypatch.delenv("MGX_NO_MF", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[0][1]).max() > 0 and out[0][0][3] < out[0][0][0]
+
+
 # ---- BASELINE config 4: rndtopo 1024x1024x64 -----------------------------------------------------------------------------
 def test_config4_rndtopo_1024x1024x64_bitwise(mg):
     """mg_testrndtopo's geometry (h = 0.2*Htot*U per cell, mg_setup_tests.f90:199; seeded generator of this build) at the
