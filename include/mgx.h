@@ -81,7 +81,9 @@ void mgx_clean(void);
 /* mg_solvers.f90:17-101 solve_p(tol,maxite).  *nite = iterations done, *res = last ||r||/||b||,
  * hist (may be NULL, else >= maxite+1 doubles) = normalised residual after each iteration, hist[0] = initial. */
 int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist);
-int mgx_fcycle(void);                     /* mg_solvers.f90:104-126 */
+/* mg_solvers.f90:104-126.  Fcycle restricts grid(1)%r on its way down: call mgx_compute_residual(1) first, as solve_p does
+ * (:50); the r a previous cycle's coarse2fine would have left there is not kept unless option "keep_r" is set. */
+int mgx_fcycle(void);
 int mgx_vcycle(int lev);                  /* mg_solvers.f90:129-151 */
 int mgx_vcycle2(int lev1, int lev2);      /* mg_solvers.f90:155-177 partial V-cycle down to lev2 */
 int mgx_relax(int lev, int nsweeps);      /* mg_relax.f90:16-47   */
@@ -147,7 +149,9 @@ int mgx_set_verbose(int level);
 
 /* Options (0/1): "warm_start" keep p between solves instead of the cold start of mg_solvers.f90:35;
  * "tictoc" per-(level,name) timers like mg_tictoc.f90 (HIP events); "exact_halos" exchange the never-read r/b halos
- * eagerly as the reference does; "verbose"; "p2p" (see below); "rb_chain" (default 1) red-black with cmatrix='real' on a
+ * eagerly as the reference does; "keep_r" (default 0) the cycles' coarse2fine also leaves the interpolated correction in the
+ * fine level's r as mg_intergrids.f90:218-226 does (dead state: compute_residual rewrites r before anything reads it; the
+ * mgx_coarse2fine operator always stores it, and so do the cycles under "exact_halos"); "verbose"; "p2p" (see below); "rb_chain" (default 1) red-black with cmatrix='real' on a
  * single-rank level: the colour passes write the next sweep's k=1 snapshot themselves, 0 = one snapshot launch per pass;
  * "rb_exact" (default 0; environment MGX_RB_EXACT): relax_method='RB' with cmatrix='real' in the reference's SEQUENTIAL
  * order (mg_relax.f90:170-186: a column reads the same-colour k=1 diagonals of plane i-1 already updated, :271-276), one

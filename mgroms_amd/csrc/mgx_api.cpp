@@ -37,7 +37,7 @@ void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *
 void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
-void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides);
+void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, double *const *, unsigned long long *const *,
@@ -138,6 +138,7 @@ struct State {
   int warm_start = 0;   // keep p between solves instead of the reference's cold start (mg_solvers.f90:35)
   int tictoc = 0;       // per-(level,name) GPU timers in the shape of mg_tictoc.f90
   int rb_chain = 1;     // red-black: chained k=1 snapshots on closed levels (0 = one snapshot launch per colour pass, for A/B tests)
+  int keep_r = 0;       // cycles also store the interpolated correction in the fine r (dead state of the reference's coarse2fine)
   int rb_exact = 0;     // red-black with cmatrix='real' in the reference's SEQUENTIAL order (plane after plane): bit-identical to mg_relax.f90:170-186, slow
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
@@ -558,17 +559,18 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
   return 0;
 }
 
-// mg_intergrids.f90:167-228
-int coarse2fine(int lev) {
+// mg_intergrids.f90:167-228.  keep_r: also leave the interpolated correction in the fine r, as the reference does (the C-ABI operator
+// and exact_halos = 1); the cycles do not -- nothing reads it before compute_residual overwrites it.
+int coarse2fine(int lev, bool keep_r = true) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0};
   if (!C.gather) {
-    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf, keep_r); S.n_launch++;
   } else {
     mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
-    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf, keep_r); S.n_launch++;
   }
-  if (S.exact_halos) CHK(fill_halo_js(F, F.v.r, true)); else F.r_halo_stale = true;
+  if (S.exact_halos && keep_r) CHK(fill_halo_js(F, F.v.r, true)); else F.r_halo_stale = true;
   // p = p + r over the whole array: the interior was updated by the kernel; the halo of p + halo of r
   // equals the halo fill of the updated p (both are images of the same interior cells)
   CHK(fill_halo_js(F, F.v.p, true));
@@ -583,7 +585,7 @@ int vcycle(int lev1) {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -597,7 +599,7 @@ int vcycle2(int lev1, int lev2) {
   }
   CHK(relax(lev2, S.par.ns_coarsest));
   for (int lev = lev2 - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -611,7 +613,7 @@ int fcycle() {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) {
-    CHK(coarse2fine(lev));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
     CHK(vcycle(lev));
   }
   return 0;
@@ -1004,11 +1006,11 @@ void mgx_clean(void) {
   for (void *q : S.allocs) (void)hipFree(q);
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1284,6 +1286,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "verbose")) S.verbose = value;
   else if (streq(name, "rb_chain")) S.rb_chain = value;
   else if (streq(name, "rb_exact")) S.rb_exact = value;
+  else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;

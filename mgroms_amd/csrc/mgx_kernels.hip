@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, doubl
 // prolongation + correction: fine r = interp(coarse p); fine p += fine r (interior).
 // mg_intergrids.f90:366-450 (tri-linear, top level x 1/2), :336-363 (nearest), :226 (p = p + r).
 // One lane = one coarse column = 2x2 fine columns.  `src` is the coarse p (or the split block).
+// WR = false: the interpolated correction is added to p without being stored in the fine r.  Inside a cycle nothing reads that r
+// before the next compute_residual rewrites it (mg_solvers.f90:129-151), and at level 1 it is a third of this kernel's traffic.
 // ------------------------------------------------------------------------------------------------
-template <bool LINEAR>
+template <bool LINEAR, bool WR>
 __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const double *__restrict__ xc, Sides ph, int stream) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int k2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
   double *__restrict__ pf = F.p;
   const int nz = C.nz;
 #define XC(kk, JJ, QQ) xc[QQ + (long long)((kk)-1) * C.RS + JJ]
-#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = ld_rt(pf + t_, stream) + v_; st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream); \
+#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = ld_rt(pf + t_, stream) + v_; if (WR) st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream); \
     const int jf_ = (PP == po) ? 2 * j2 - 1 : 2 * j2, if_ = (OO == o0) ? i : i + 1; \
-    mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
+    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
   if (!LINEAR) {
     const double v = XC(k2, c0, q0);
     const int k = 2 * k2 - 1;
@@ -632,11 +634,13 @@ void mgxk_dot(hipStream_t st, const LevView *L, const double *a, const double *b
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {
   hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero);
 }
-void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph) {
+void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r) {
   const int by = C->nz >= 4 ? 4 : C->nz;
   dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
-  if (linear) hipLaunchKernelGGL((k_coarse2fine<true>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F));
-  else hipLaunchKernelGGL((k_coarse2fine<false>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F));
+#define C2F(LIN, WRV) hipLaunchKernelGGL((k_coarse2fine<LIN, WRV>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F))
+  if (linear) { if (keep_r) C2F(true, true); else C2F(true, false); }
+  else { if (keep_r) C2F(false, true); else C2F(false, false); }
+#undef C2F
 }
 void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
   const int n = L->nx + L->ny + 1;

@@ -4,50 +4,56 @@
 // thread per column: in a four-colour pass a quarter of the threads work, three waves idle at the barrier, 0.56 us per pass.
 // Here a level of <= 256 columns is ONE wave: every lane owns a 2x2 block of columns, i.e. one column of each of the four
 // colours (two of each red-black colour), so all 64 lanes work in every pass and the passes are separated by a
-// single-wave barrier only.  Everything that does not change between passes -- b, the own slots and pivots, the slots of the
+// single-wave barrier only.  The level above it (32x32x4, 1024 columns) runs the same way on four waves of one workgroup
+// (k_relax_small re-read every operand through L2 there: 4.5 us per pass).  Everything that does not change between passes -- b, the own slots and pivots, the slots of the
 // j+1 / i+1 neighbours, gam -- sits in registers (4 columns x NZ rows x 16 values); p lives in LDS with its mirrored halo.
 // Same expressions in the same order as relax_col_nz / k_relax_reg: bit-identical.
 #include <cstdlib>
 
 #include "mgx_device.h"
 
-template <int NZ, bool REAL>
-__global__ __launch_bounds__(64, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph) {
+template <int NZ, bool REAL, int NT>
+__global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph) {
   extern __shared__ double ldsw[];
   const int nx = G.nx, ny = G.ny, W = ny + 2, PL = (nx + 2) * W;  // P[k][i][j]
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
   const int lane = threadIdx.x;
 #define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
-  for (int t = lane; t < NZ * PL; t += WAVE) {
+  for (int t = lane; t < NZ * PL; t += NT) {
     const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W;
     P[t] = G.p[GI(k0, j, i)];
   }
   const int nbj = ny >> 1;
   const bool mine = lane < (nx >> 1) * nbj;
   const int bi = lane / nbj, bj = lane - bi * nbj;
-  // column q of the lane: (i,j) = (2 bi + 1 + (q >> 1), 2 bj + 1 + (q & 1)); q = 0..3 are the four colours in the reference's order
-  double ob[4][NZ], a2[4][NZ], a3[4][NZ], a4[4][NZ], a5[4][NZ], a6[4][NZ], a7[4][NZ], a8[4][NZ], bet[4][NZ], g[4][NZ];
-  double r3[4][NZ], r4[4][NZ], r5[4][NZ], r6[4][NZ], r7[4][NZ], r8[4][NZ], e2[4], e4[4];
+  // column q of the lane: (i,j) = (2 bi + 1 + (q >> 1), 2 bj + 1 + (q & 1)); q = 0..3 are the four colours in the reference's order.
+  // The symmetric storage makes a column read slots 3,4,5 of its j+1 neighbour and 6,7,8 of its i+1 neighbour: inside the block those
+  // are the lane's own registers (q -> q+1, q -> q+2), only the columns j+2 / i+2 beyond the block are held separately (xj, xi).
+  double ob[4][NZ], a2[4][NZ], a3[4][NZ], a4[4][NZ], a5[4][NZ], a6[4][NZ], a7[4][NZ], a8[4][NZ], bet[4][NZ];
+  double xj[2][3][NZ], xi[2][3][NZ], e2[4], e4[4];
   if (mine) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = 2 * bi + 1 + (q >> 1), j = 2 * bj + 1 + (q & 1);
 #pragma unroll
       for (int k = 0; k < NZ; k++) {
-        const long long c = GI(k, j, i), cj = GI(k, j + 1, i), ci = GI(k, j, i + 1);
+        const long long c = GI(k, j, i);
         ob[q][k] = G.b[c]; a2[q][k] = G.cA[1][c]; a3[q][k] = G.cA[2][c]; a4[q][k] = G.cA[3][c]; a5[q][k] = G.cA[4][c];
         a6[q][k] = G.cA[5][c]; a7[q][k] = G.cA[6][c]; a8[q][k] = G.cA[7][c]; bet[q][k] = G.bet[c];
-        r3[q][k] = G.cA[2][cj]; r4[q][k] = G.cA[3][cj]; r5[q][k] = G.cA[4][cj];
-        r6[q][k] = G.cA[5][ci]; r7[q][k] = G.cA[6][ci]; r8[q][k] = G.cA[7][ci];
+        if (q & 1) { const long long cj = GI(k, j + 1, i); xj[q >> 1][0][k] = G.cA[2][cj]; xj[q >> 1][1][k] = G.cA[3][cj]; xj[q >> 1][2][k] = G.cA[4][cj]; }
+        if (q >> 1) { const long long ci = GI(k, j, i + 1); xi[q & 1][0][k] = G.cA[5][ci]; xi[q & 1][1][k] = G.cA[6][ci]; xi[q & 1][2][k] = G.cA[7][ci]; }
       }
       e2[q] = e4[q] = 0.0;
       if (REAL) { e2[q] = G.cA[4][GI(0, j - 1, i + 1)]; e4[q] = G.cA[7][GI(0, j + 1, i + 1)]; }
-      g[q][0] = 0.0;
-#pragma unroll
-      for (int k = 1; k < NZ; k++) g[q][k] = a2[q][k] * bet[q][k - 1];  // gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325)
     }
   }
   __syncthreads();
+#define R3(q, k) (((q) & 1) ? xj[(q) >> 1][0][k] : a3[((q) + 1) & 3][k])
+#define R4(q, k) (((q) & 1) ? xj[(q) >> 1][1][k] : a4[((q) + 1) & 3][k])
+#define R5(q, k) (((q) & 1) ? xj[(q) >> 1][2][k] : a5[((q) + 1) & 3][k])
+#define R6(q, k) (((q) >> 1) ? xi[(q) & 1][0][k] : a6[((q) + 2) & 3][k])
+#define R7(q, k) (((q) >> 1) ? xi[(q) & 1][1][k] : a7[((q) + 2) & 3][k])
+#define R8(q, k) (((q) >> 1) ? xi[(q) & 1][2][k] : a8[((q) + 2) & 3][k])
   // one column solve; Q1 = where the k=1 horizontal diagonals are read (the snapshot for red-black, p itself for four-colour)
 #define COLUMN(q)                                                                                                          \
   {                                                                                                                         \
@@ -65,24 +71,25 @@ __global__ __launch_bounds__(64, 1) void k_relax_wave(LevView G, int nsweeps, in
     _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
       double rhs;                                                                                                           \
       if (k == 0) {                                                                                                         \
-        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k] - r5[q][k + 1] * pjp[k + 1]          \
-                       - a6[q][k] * pim[k + 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k] - r8[q][k + 1] * pip[k + 1];          \
+        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - a4[q][k] * pjm[k] - R4(q, k) * pjp[k] - R5(q, k + 1) * pjp[k + 1]          \
+                       - a6[q][k] * pim[k + 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k] - R8(q, k + 1) * pip[k + 1];          \
         if (REAL) rhs = rhs - a5[q][0] * d1 - e2[q] * d2 - a8[q][0] * d3 - e4[q] * d4;                                      \
         xv = rhs * bet[q][k];                                                                                               \
       } else if (k < NZ - 1) {                                                                                              \
-        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - r3[q][k - 1] * pjp[k - 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k]          \
-                       - a5[q][k] * pjm[k - 1] - r5[q][k + 1] * pjp[k + 1]                                                  \
-                       - a6[q][k] * pim[k + 1] - r6[q][k - 1] * pip[k - 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k]          \
-                       - a8[q][k] * pim[k - 1] - r8[q][k + 1] * pip[k + 1];                                                 \
+        rhs = ob[q][k] - a3[q][k] * pjm[k + 1] - R3(q, k - 1) * pjp[k - 1] - a4[q][k] * pjm[k] - R4(q, k) * pjp[k]          \
+                       - a5[q][k] * pjm[k - 1] - R5(q, k + 1) * pjp[k + 1]                                                  \
+                       - a6[q][k] * pim[k + 1] - R6(q, k - 1) * pip[k - 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k]          \
+                       - a8[q][k] * pim[k - 1] - R8(q, k + 1) * pip[k + 1];                                                 \
         xv = (rhs - a2[q][k] * xv) * bet[q][k];                                                                             \
       } else {                                                                                                              \
-        rhs = ob[q][k] - r3[q][k - 1] * pjp[k - 1] - a4[q][k] * pjm[k] - r4[q][k] * pjp[k] - a5[q][k] * pjm[k - 1]          \
-                       - r6[q][k - 1] * pip[k - 1] - a7[q][k] * pim[k] - r7[q][k] * pip[k] - a8[q][k] * pim[k - 1];          \
+        rhs = ob[q][k] - R3(q, k - 1) * pjp[k - 1] - a4[q][k] * pjm[k] - R4(q, k) * pjp[k] - a5[q][k] * pjm[k - 1]          \
+                       - R6(q, k - 1) * pip[k - 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k] - a8[q][k] * pim[k - 1];          \
         xv = (rhs - a2[q][k] * xv) * bet[q][k];                                                                             \
       }                                                                                                                     \
       x[k] = xv;                                                                                                            \
     }                                                                                                                       \
-    _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - g[q][k + 1] * x[k + 1];                               \
+    /* gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325): the same product as the stored pivot table, recomputed */              \
+    _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - (a2[q][k + 1] * bet[q][k]) * x[k + 1];                \
     _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
       const int o = k * PL;                                                                                                 \
       const double v = x[k];                                                                                                \
@@ -106,16 +113,22 @@ __global__ __launch_bounds__(64, 1) void k_relax_wave(LevView G, int nsweeps, in
       __syncthreads();
     } else {  // red-black (mg_relax.f90:170-186), parallel semantics: same-colour k=1 diagonals from the snapshot taken before the pass
       const double *__restrict__ Q1 = REAL ? P1 : P;
-      if (REAL) { for (int t = lane; t < PL; t += WAVE) P1[t] = P[t]; __syncthreads(); }
+      if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(0) COLUMN(3) }   // rb = 1: j = 1+mod(i+1,2): (i odd, j odd) and (i even, j even)
       __syncthreads();
-      if (REAL) { for (int t = lane; t < PL; t += WAVE) P1[t] = P[t]; __syncthreads(); }
+      if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(1) COLUMN(2) }   // rb = 2
       __syncthreads();
     }
   }
 #undef COLUMN
-  for (int t = lane; t < NZ * PL; t += WAVE) {
+#undef R3
+#undef R4
+#undef R5
+#undef R6
+#undef R7
+#undef R8
+  for (int t = lane; t < NZ * PL; t += NT) {
     const int k0 = t / PL, r = t - k0 * PL, ii = r / W, jj = r - ii * W;
     G.p[GI(k0, jj, ii)] = P[t];
   }
@@ -124,15 +137,22 @@ __global__ __launch_bounds__(64, 1) void k_relax_wave(LevView G, int nsweeps, in
 
 extern "C" {
 
-// returns 1 when launched: a closed level of <= 256 columns with nz = 2 (the coarsest grid of every BASELINE configuration)
+// returns 1 when launched: a closed level of <= 256 columns with nz = 2 (the coarsest grid of every BASELINE configuration) as one
+// wave, or of <= 1024 columns with nz = 2 / 4 (the 32x32x4 level above it) as four waves
 int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
-  static const bool off = getenv("MGX_NO_WAVE") != nullptr;
-  if (off || L->nz != 2 || method == 0 || (exact && method == 1 && real)) return 0;
-  if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || (L->nx / 2) * (L->ny / 2) > WAVE) return 0;
+  static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr;
+  if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (exact && method == 1 && real)) return 0;
+  const int nblk = (L->nx / 2) * (L->ny / 2);
+  if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || nblk > 4 * WAVE) return 0;
+  if ((nblk > WAVE || L->nz == 4) && off4) return 0;
   const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
-  if (real) hipLaunchKernelGGL((k_relax_wave<2, true>), dim3(1), dim3(WAVE), bytes, st, *L, nsweeps, method, ph);
-  else hipLaunchKernelGGL((k_relax_wave<2, false>), dim3(1), dim3(WAVE), bytes, st, *L, nsweeps, method, ph);
-  return 1;
+#define WAVE_CASE(NZV, NTV)                                                                                                   \
+  { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);      \
+    else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);          \
+    return 1; }
+  if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else WAVE_CASE(2, 256) }
+  if (nblk <= WAVE) WAVE_CASE(4, 64) else WAVE_CASE(4, 256)
+#undef WAVE_CASE
 }
 
 }  // extern "C"

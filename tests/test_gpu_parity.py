@@ -509,9 +509,32 @@ def test_vcycle2_and_fcycle_ops(mg):
     o.compute_rhs()
     mg.Vcycle2(1, mg.nlevs()); o.vcycle(1)
     assert np.array_equal(mg.grid(1).p, o.field("p"))
+    # Fcycle starts by restricting grid(1)%r (mg_solvers.f90:110-114): solve_p computes the residual first (:50), so does this test
+    mg.compute_residual(1); o.residual(1)
     mg.Fcycle(); o.fcycle()
     assert np.array_equal(mg.grid(1).p, o.field("p"))
     for lev in range(2, o.nlevs + 1):
+        assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
+
+
+def test_cycle_keeps_the_dead_r_on_request(mg):
+    # coarse2fine leaves the interpolated correction in the fine r (mg_intergrids.f90:218-226); nothing reads it before the next
+    # compute_residual, so the cycles skip that store unless "keep_r" (or "exact_halos") asks for the reference's state
+    o = _setup(mg, 32, 32, 16)
+    u, v, w = _uvw(32, 32, 16)
+    mg.nhydro.compute_rhs(u, v, w)
+    o.field("w")[...] = w
+    o.compute_rhs()
+    mg.nhydro.set_option("keep_r", 1)
+    try:
+        mg.Vcycle(1); o.vcycle(1)
+        for lev in range(1, o.nlevs):
+            assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
+            assert np.array_equal(mg.grid(lev).r[1:-1, 1:-1, :], o.field("r", lev)[1:-1, 1:-1, :]), lev
+    finally:
+        mg.nhydro.set_option("keep_r", 0)
+    mg.Vcycle(1); o.vcycle(1)
+    for lev in range(1, o.nlevs + 1):
         assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
 
 
