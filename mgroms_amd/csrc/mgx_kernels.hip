@@ -334,6 +334,109 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
 #undef PUT
 }
 
+// Tri-linear prolongation + correction, one lane = a run of KC coarse levels of one coarse column.
+// k_coarse2fine above fetches 18 coarse values per lane for 8 fine cells (the 3x3 neighbourhood of two coarse levels): 2.25
+// cache accesses per fine cell next to the one load and one store the cell itself needs -- the texture path was busy 80 % of
+// the kernel (rocprofv3 MemUnitStalled) and the level-1 launch ran at 4 TB/s.  Here a lane reads only its OWN column of the three
+// coarse planes i2-1, i2, i2+1, takes the j2-1 / j2+1 columns from its neighbour lanes (the first and last lane of the wave
+// fetch theirs), and keeps a three-level window while it walks up: 3 / (8 KC) coarse loads per fine cell instead of 2.25; the fine
+// p of the next coarse level are requested before the current level is stored (without that look-ahead the run is a chain of
+// load -> store round trips and loses: 106 us; with it 71 us against 83 us of k_coarse2fine at 512x512x64, WR = false).
+// Same expressions in the same order as above (mg_intergrids.f90:392-446): bit-identical.
+template <bool WR>
+__global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, const double *__restrict__ xc, Sides ph, int stream, int KC) {
+  const int lane = threadIdx.x;
+  const int j2 = 1 + blockIdx.x * WAVE + lane;
+  const int i2 = 1 + blockIdx.z;
+  const int nz = C.nz;
+  const int ka = 1 + (blockIdx.y * blockDim.y + threadIdx.y) * KC;   // wave-uniform
+  if (ka > nz) return;
+  const int kb = ka + KC - 1 < nz ? ka + KC - 1 : nz;
+  const bool live = j2 <= C.ny;
+  const int jl = live ? j2 : C.ny + 1;  // lanes past the row still hand their neighbour a value (the halo column ny+1)
+  const int i = 2 * i2 - 1;
+  const int po = F.HO + (j2 - 1), pe = F.EO + j2;  // fine j (odd) and j+1 (even)
+  const int c0 = jpos(C, jl), cm = jpos(C, jl - 1), cp = jpos(C, jl + 1 <= C.ny + 1 ? jl + 1 : jl);
+  const long long q0 = (long long)i2 * C.plane, qm = q0 - C.plane, qp = q0 + C.plane;
+  const long long o0 = (long long)i * F.plane, o1 = o0 + F.plane;
+  double *__restrict__ rf = F.r;
+  double *__restrict__ pf = F.p;
+  // one coarse level: v[3*a + b], a = plane (i2-1, i2, i2+1), b = column (j2-1, j2, j2+1)
+#define ROW(kk, v)                                                                                                  \
+  {                                                                                                                 \
+    const long long ro_ = (long long)((kk)-1) * C.RS;                                                               \
+    const double t0_ = xc[qm + ro_ + c0], t1_ = xc[q0 + ro_ + c0], t2_ = xc[qp + ro_ + c0];                         \
+    v[1] = t0_; v[4] = t1_; v[7] = t2_;                                                                             \
+    v[0] = __shfl_up(t0_, 1, WAVE); v[3] = __shfl_up(t1_, 1, WAVE); v[6] = __shfl_up(t2_, 1, WAVE);                 \
+    v[2] = __shfl_down(t0_, 1, WAVE); v[5] = __shfl_down(t1_, 1, WAVE); v[8] = __shfl_down(t2_, 1, WAVE);           \
+    if (lane == 0) { v[0] = xc[qm + ro_ + cm]; v[3] = xc[q0 + ro_ + cm]; v[6] = xc[qp + ro_ + cm]; }                \
+    if (lane == WAVE - 1) { v[2] = xc[qm + ro_ + cp]; v[5] = xc[q0 + ro_ + cp]; v[8] = xc[qp + ro_ + cp]; }         \
+  }
+  // the eight fine p of coarse level kk: [4*half + 2*(plane i+1) + (column j+1)], loaded one level ahead of their use
+#define LOADP(kk, v)                                                                                                \
+  if (live) {                                                                                                       \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                              \
+      const long long ro_ = (long long)(2 * (kk) - 2 + h_) * F.RS;                                                  \
+      v[4 * h_ + 0] = ld_rt(pf + o0 + ro_ + po, stream); v[4 * h_ + 1] = ld_rt(pf + o0 + ro_ + pe, stream);         \
+      v[4 * h_ + 2] = ld_rt(pf + o1 + ro_ + po, stream); v[4 * h_ + 3] = ld_rt(pf + o1 + ro_ + pe, stream);         \
+    }                                                                                                               \
+  }
+#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = pc[4 * half + 2 * (OO == o1) + (PP == pe)] + v_; if (WR) st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream); \
+    const int jf_ = (PP == po) ? 2 * j2 - 1 : 2 * j2, if_ = (OO == o0) ? i : i + 1; \
+    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
+  const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
+  double pc[8], pa[8], pb[8];  // fine p of the level in work and of the next one (two levels ahead measured slower: 76 vs 71 us)
+  double lo[9], x[9], hi[9];  // coarse levels k2-1, k2, k2+1
+#pragma unroll
+  for (int q = 0; q < 9; q++) lo[q] = hi[q] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) pa[q] = pb[q] = 0.0;
+  LOADP(ka, pa)
+  if (ka > 1) ROW(ka - 1, lo)
+  ROW(ka, x)
+  // one coarse level: CUR holds its fine p, NXT receives those of level kk + 1
+#define STEP(kk, CUR, NXT)                                                                                          \
+  {                                                                                                                 \
+    const int k2 = (kk);                                                                                            \
+    if (k2 + 1 <= kb) LOADP(k2 + 1, NXT)                                                                            \
+    if (k2 < nz) ROW(k2 + 1, hi)                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 8; q++) pc[q] = CUR[q];                                                   \
+    if (live) {                                                                                                     \
+      const double xmm = x[0], x0m = x[1], xpm = x[2], xm0 = x[3], x00 = x[4], xp0 = x[5], xmp = x[6], x0p = x[7], xpp = x[8]; \
+      _Pragma("unroll") for (int half = 0; half < 2; half++) {                                                      \
+        const int k = 2 * k2 - 1 + half;  /* fine level */                                                          \
+        if (k == 1) {                      /* bottom level: bilinear (mg_intergrids.f90:392-405) */                  \
+          PUT(1, o0, po, +a * x00 + c * xmm + b * xm0 + b * x0m);                                                   \
+          PUT(1, o0, pe, +a * x00 + c * xpm + b * xp0 + b * x0m);                                                   \
+          PUT(1, o1, po, +a * x00 + c * xmp + b * xm0 + b * x0p);                                                   \
+          PUT(1, o1, pe, +a * x00 + c * xpp + b * xp0 + b * x0p);                                                   \
+        } else if (k == 2 * nz) {          /* top level: 1/2 bilinear (:434-446) */                                  \
+          PUT(k, o0, po, 0.5 * (a * x00 + c * xmm + b * xm0 + b * x0m));                                            \
+          PUT(k, o0, pe, 0.5 * (a * x00 + c * xpm + b * xp0 + b * x0m));                                            \
+          PUT(k, o1, po, 0.5 * (a * x00 + c * xmp + b * xm0 + b * x0p));                                            \
+          PUT(k, o1, pe, 0.5 * (a * x00 + c * xpp + b * xp0 + b * x0p));                                            \
+        } else {                           /* interior: tri-linear, kp = k2-1 for odd k, k2+1 for even k (:407-432) */ \
+          const double *__restrict__ y = half ? hi : lo;                                                            \
+          const double ymm = y[0], y0m = y[1], ypm = y[2], ym0 = y[3], y00 = y[4], yp0 = y[5], ymp = y[6], y0p = y[7], ypp = y[8]; \
+          PUT(k, o0, po, +d * x00 + f * xmm + e * xm0 + e * x0m + e * y00 + g * ymm + f * ym0 + f * y0m);           \
+          PUT(k, o0, pe, +d * x00 + f * xpm + e * xp0 + e * x0m + e * y00 + g * ypm + f * yp0 + f * y0m);           \
+          PUT(k, o1, po, +d * x00 + f * xmp + e * xm0 + e * x0p + e * y00 + g * ymp + f * ym0 + f * y0p);           \
+          PUT(k, o1, pe, +d * x00 + f * xpp + e * xp0 + e * x0p + e * y00 + g * ypp + f * yp0 + f * y0p);           \
+        }                                                                                                           \
+      }                                                                                                             \
+    }                                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 9; q++) { lo[q] = x[q]; x[q] = hi[q]; }                                   \
+  }
+  for (int kk = ka; kk <= kb; kk += 2) {
+    STEP(kk, pa, pb)
+    if (kk + 1 <= kb) STEP(kk + 1, pb, pa)
+  }
+#undef STEP
+#undef ROW
+#undef PUT
+#undef LOADP
+}
+
 // ------------------------------------------------------------------------------------------------
 // physical-boundary halo (homogeneous Neumann mirror), nh = 1.  mg_mpi_exchange.f90:509-537 (edges),
 // :552,567,582,597 (corners where both sides are physical).  All sources are interior cells.
@@ -635,6 +738,22 @@ void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double
   hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero);
 }
 void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r) {
+  static const bool norun = getenv("MGX_C2F_OLD") != nullptr;
+  if (linear && !norun) {
+    // runs of KC coarse levels per lane: long enough to amortise the three-level window, short enough to keep >= ~2 waves per SIMD
+    static const int kcenv = getenv("MGX_C2F_KC") ? atoi(getenv("MGX_C2F_KC")) : 0;
+    int KC = kcenv > 0 ? kcenv : 16;
+    const long long wav = (long long)((C->ny + WAVE - 1) / WAVE) * C->nx;
+    while (KC > 1 && wav * ((C->nz + KC - 1) / KC) < 2048) KC >>= 1;
+    if (KC > C->nz) KC = C->nz;
+    const int nrun = (C->nz + KC - 1) / KC, byr = nrun >= 4 ? 4 : nrun;
+    dim3 blk(WAVE, byr), grd((C->ny + WAVE - 1) / WAVE, (nrun + byr - 1) / byr, C->nx);
+    static const int ntenv = getenv("MGX_C2F_NT") ? atoi(getenv("MGX_C2F_NT")) : -1;  // A/B: force the streaming hints on / off
+    const int nt = ntenv >= 0 ? ntenv : level_streams(F);
+    if (keep_r) hipLaunchKernelGGL((k_coarse2fine_run<true>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    else hipLaunchKernelGGL((k_coarse2fine_run<false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    return;
+  }
   const int by = C->nz >= 4 ? 4 : C->nz;
   dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
 #define C2F(LIN, WRV) hipLaunchKernelGGL((k_coarse2fine<LIN, WRV>), grd, blk, 0, st, *F, *C, src, ph, level_streams(F))
