@@ -26,6 +26,7 @@ struct RectOp { int op, nzz, nh, ny, j0, j1, i0, i1, mj, cj, mi, ci, mj2, cj2, m
 struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 
 extern "C" {
+int mgxk_relax_ks_pair(hipStream_t, const LevView *, int, int, int, Sides);
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
@@ -471,11 +472,14 @@ int relax(int lev, int nsweeps) {
       }
       if (chain) { L.v.p1 = L.v.p1w; L.v.p1w = nullptr; if (it == nsweeps) L.v.p1 = p1a; }
     } else {
-      for (int fc1 = 1; fc1 <= 2; fc1++)
+      for (int fc1 = 1; fc1 <= 2; fc1++) {
+        // closed mid levels: the two colours of a plane set in one launch (mgx_relax_ks.hip)
+        if (closed && mgxk_relax_ks_pair(S.stream, &L.v, fc1, L.nx / 2, S.real, ph)) { S.n_launch++; continue; }
         for (int fc2 = 1; fc2 <= 2; fc2++) {
           const int fused = mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0, ph); S.n_launch++;
           CHK(fill_halo_js(L, L.v.p, fused));
         }
+      }
     }
   }
   return 0;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
     ipl = xcd * (nplanes >> 3) + local / gx;
     bx = local - (local / gx) * gx;
   } else { ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }
-  const int lane = threadIdx.x, w = threadIdx.y;
+  const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row ranges in scalar registers
   const int jh = bx * WAVE + lane;
   const bool live = jh < (L.ny >> 1);  // ragged last chunk: dead lanes still join the barriers
   const int i = i0 + istep * ipl;
@@ -51,12 +51,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
   if (live) {
 #pragma unroll
     for (int r = 0; r < R + 2; r++) {
-      const int k = ka - 1 + r;
-      if (k >= 1 && k <= NZ) {
-        const long long ro = (long long)(k - 1) * RS;
-        pjm[r] = p[o + ro + jm]; pim[r] = p[om + ro + c]; pjp[r] = p[o + ro + jp]; pip[r] = p[op + ro + c];
-        zyo[r] = zy[o + ro + c]; zxo[r] = zx[o + ro + c];
-      } else { pjm[r] = pim[r] = pjp[r] = pip[r] = zyo[r] = zxo[r] = 0.0; }
+      // rows 0 and NZ+1 do not exist and are never used (the first and the last row have their own expressions): clamped, no branch
+      const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+      const long long ro = (long long)(k - 1) * RS;
+      pjm[r] = p[o + ro + jm]; pim[r] = p[om + ro + c]; pjp[r] = p[o + ro + jp]; pip[r] = p[op + ro + c];
+      zyo[r] = zy[o + ro + c]; zxo[r] = zx[o + ro + c];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -157,6 +156,188 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two colours of the four-colour sweep in one launch.  Colours 1 and 2 (mg_relax.f90:214-217: i odd with j odd, then i odd with
+// j even) touch the same planes, and the second reads nothing the first changes except its j-1 / j+1 neighbours in the SAME plane
+// (the planes i-1, i+1 belong to colours 3 and 4) -- and, on a physical west / east boundary, the k=1 diagonals in the mirrored
+// halo plane.  So one workgroup that owns a whole plane (ny/2 <= 64 columns per colour: the 128x128x16 and 64x64x8 levels) runs
+// colour a, keeps its result in LDS, and runs colour b from there; everything else colour b needs is requested at the start and
+// arrives while colour a is computed.  The mid levels are launch- and latency-bound (6 and 4.8 us per pass for 4096 and 1024
+// columns): 10 launches per V-cycle-level instead of 20.  Closed levels only (no exchange between the two colours).
+// Same expressions in the same order: bit-identical to the two separate passes.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int R>
+struct KsRows {
+  double pim[R + 2], pip[R + 2], zyo[R + 2], zxo[R + 2];  // rows ka-1 .. ka+R
+  double bb[R], a4o[R], a7o[R], a4n[R], a7n[R], zyjm[R], zyjp[R], zxim[R], zxip[R], oa2[R], obt[R];
+  double e1, e2, e3, e4;
+};
+// everything of rows ka .. ka+R-1 that colour a does not change (the j-1 / j+1 neighbours of p and the k=1 diagonals are the caller's)
+template <int NZ, int R, bool REAL>
+__device__ __forceinline__ void ks_load(KsRows<R> &q, const LevView &L, const long long o, const int c, const int jm, const int jp, const int ka, const bool diag) {
+  const long long RS = L.RS, om = o - L.plane, op = o + L.plane;
+  const double *__restrict__ p = L.p, *__restrict__ b = L.b;
+  const double *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4], *__restrict__ a7 = L.cA[6],
+               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
+#pragma unroll
+  for (int r = 0; r < R + 2; r++) {
+    // rows 0 and NZ+1 do not exist and are never used (the first and the last row have their own expressions): clamped, no branch
+    const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+    const long long ro = (long long)(k - 1) * RS;
+    q.pim[r] = p[om + ro + c]; q.pip[r] = p[op + ro + c];
+    q.zyo[r] = zy[o + ro + c]; q.zxo[r] = zx[o + ro + c];
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const long long ro = (long long)(ka + r - 1) * RS;
+    q.bb[r] = b[o + ro + c]; q.a4o[r] = a4[o + ro + c]; q.a7o[r] = a7[o + ro + c];
+    q.a4n[r] = a4[o + ro + jp]; q.a7n[r] = a7[op + ro + c];
+    q.zyjm[r] = zy[o + ro + jm]; q.zyjp[r] = zy[o + ro + jp]; q.zxim[r] = zx[om + ro + c]; q.zxip[r] = zx[op + ro + c];
+    q.oa2[r] = a2[o + ro + c]; q.obt[r] = bet[o + ro + c];
+  }
+  q.e1 = q.e2 = q.e3 = q.e4 = 0.0;
+  if (REAL && diag) {  // the wave that owns row 1: coefficients of the four k=1 horizontal diagonals (mg_relax.f90:271-276)
+    q.e1 = a5[o + c]; q.e2 = a5[op + jm]; q.e3 = a8[o + c]; q.e4 = a8[op + jp];
+  }
+}
+template <int NZ, int R, bool REAL>
+__device__ __forceinline__ void ks_rhs(const KsRows<R> &q, const double *pjm, const double *pjp, const double d1, const double d2, const double d3, const double d4,
+                                       const int ka, const int lane, double *__restrict__ sh, double *__restrict__ sa2, double *__restrict__ sbt) {
+  const double qrt = 0.25;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int k = ka + r;
+    const double pjm_m = pjm[r], pjm_0 = pjm[r + 1], pjm_p = pjm[r + 2], pim_m = q.pim[r], pim_0 = q.pim[r + 1], pim_p = q.pim[r + 2];
+    const double pjp_m = pjp[r], pjp_0 = pjp[r + 1], pjp_p = pjp[r + 2], pip_m = q.pip[r], pip_0 = q.pip[r + 1], pip_p = q.pip[r + 2];
+    const double zy_m = q.zyo[r], zy_p = q.zyo[r + 2], zx_m = q.zxo[r], zx_p = q.zxo[r + 2];
+    const double c3 = qrt * (zy_p + q.zyjm[r]), c3m = qrt * (q.zyjp[r] + zy_m), c5 = -qrt * (zy_m + q.zyjm[r]), c5m = -qrt * (q.zyjp[r] + zy_p);
+    const double c6 = qrt * (zx_p + q.zxim[r]), c6m = qrt * (q.zxip[r] + zx_m), c8 = -qrt * (zx_m + q.zxim[r]), c8m = -qrt * (q.zxip[r] + zx_p);
+    double rhs;
+    if (k == 1) {
+      rhs = q.bb[r] - c3 * pjm_p - q.a4o[r] * pjm_0 - q.a4n[r] * pjp_0 - c5m * pjp_p
+                    - c6 * pim_p - q.a7o[r] * pim_0 - q.a7n[r] * pip_0 - c8m * pip_p;
+      if (REAL) rhs = rhs - q.e1 * d1 - q.e2 * d2 - q.e3 * d3 - q.e4 * d4;
+    } else if (k < NZ) {
+      rhs = q.bb[r] - c3 * pjm_p - c3m * pjp_m - q.a4o[r] * pjm_0 - q.a4n[r] * pjp_0
+                    - c5 * pjm_m - c5m * pjp_p
+                    - c6 * pim_p - c6m * pip_m - q.a7o[r] * pim_0 - q.a7n[r] * pip_0
+                    - c8 * pim_m - c8m * pip_p;
+    } else {
+      rhs = q.bb[r] - c3m * pjp_m - q.a4o[r] * pjm_0 - q.a4n[r] * pjp_0 - c5 * pjm_m
+                    - c6m * pip_m - q.a7o[r] * pim_0 - q.a7n[r] * pip_0 - c8 * pim_m;
+    }
+    sh[(k - 1) * WAVE + lane] = rhs;
+    sa2[(k - 1) * WAVE + lane] = q.oa2[r];
+    sbt[(k - 1) * WAVE + lane] = q.obt[r];
+  }
+}
+// tridiag (mg_relax.f90:322-332) on the parked right-hand sides of one lane; x(k) goes to out[(k-1)*stride + lane]
+template <int NZ>
+__device__ __forceinline__ void ks_tridiag(const double *sh, const double *__restrict__ sa2, const double *__restrict__ sbt, const int lane,
+                                           double *out, const int stride) {  // out may be sh itself
+  double x[NZ], g[NZ], ra2[NZ], rbt[NZ];
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) { x[k - 1] = sh[(k - 1) * WAVE + lane]; ra2[k - 1] = sa2[(k - 1) * WAVE + lane]; rbt[k - 1] = sbt[(k - 1) * WAVE + lane]; }
+  double xv = x[0] * rbt[0];
+  x[0] = xv;
+  g[0] = 0.0;
+#pragma unroll
+  for (int k = 2; k <= NZ; k++) {
+    g[k - 1] = ra2[k - 1] * rbt[k - 2];                 // gam(k) = dd(k-1)*bet(k-1)
+    xv = (x[k - 1] - ra2[k - 1] * xv) * rbt[k - 1];     // xc(k) = (b(k) - dd(k-1)*xc(k-1))*bet(k)
+    x[k - 1] = xv;
+  }
+#pragma unroll
+  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) out[(k - 1) * stride + lane] = x[k - 1];
+}
+// store rows ka .. ka+R-1 of a column and the physical-boundary mirrors (mg_mpi_exchange.f90:509-537,552-597)
+template <int R>
+__device__ __forceinline__ void ks_store(const LevView &L, const long long o, const int c, const int i, const int j, const int ka, const int lane,
+                                         const double *__restrict__ x, const int stride, const Sides ph) {
+  double *__restrict__ p = L.p;
+  const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  const int cS = L.EO, cN = jpos(L, L.ny + 1);
+  const long long oW = 0, oE = (long long)(L.nx + 1) * L.plane;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int k = ka + r;
+    const long long ro = (long long)(k - 1) * L.RS;
+    const double v = x[(k - 1) * stride + lane];
+    p[o + ro + c] = v;
+    if (mS) p[o + ro + cS] = v;
+    if (mN) p[o + ro + cN] = v;
+    if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
+    if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
+  }
+}
+}  // namespace
+
+template <int NZ, int NW, bool REAL>
+__global__ __launch_bounds__(64 * NW, 1) void k_relax_ks2(LevView L, int i0, int nplanes, Sides ph) {
+  constexpr int R = NZ / NW;     // rows per wave
+  constexpr int XS = WAVE + 1;   // colour a's result: [k-1][lane], slot nh = the halo column ny+1 behind the last column
+  __shared__ double sh[NZ * WAVE], sa2[NZ * WAVE], sbt[NZ * WAVE], xa[NZ * XS];
+  int ipl = blockIdx.x;
+  if ((nplanes & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; ipl = xcd * (nplanes >> 3) + local; }  // contiguous planes per XCD
+  const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row ranges in scalar registers
+  const int nh = L.ny >> 1;      // columns of one colour in a plane (<= 64)
+  const bool live = lane < nh;
+  const int i = i0 + 2 * ipl;
+  const long long o = (long long)i * L.plane;
+  const int ka = w * R + 1;
+  // colour a: j = 2 lane + 1 ; colour b: j = 2 lane + 2, whose j-1 / j+1 neighbours are colour a's columns lane and lane + 1
+  const int cA = L.HO + lane, jmA = L.EO + lane, jpA = jmA + 1;
+  const int cB = L.EO + lane + 1, jmB = L.HO + lane, jpB = jmB + 1;
+  const bool mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  KsRows<R> A, B;
+  double pjm[R + 2] = {}, pjp[R + 2] = {}, d1 = 0, d2 = 0, d3 = 0, d4 = 0;     // colour a: from memory
+  double bd1 = 0, bd2 = 0, bd3 = 0, bd4 = 0;                          // colour b's k=1 diagonals when they sit in unchanged planes
+  const long long om = o - L.plane, op = o + L.plane;
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < R + 2; r++) {
+      const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+      pjm[r] = L.p[o + (long long)(k - 1) * L.RS + jmA]; pjp[r] = L.p[o + (long long)(k - 1) * L.RS + jpA];
+    }
+    if (REAL && w == 0) {
+      d1 = L.p[om + jpA]; d2 = L.p[op + jmA]; d3 = L.p[om + jmA]; d4 = L.p[op + jpA];
+      bd1 = L.p[om + jpB]; bd2 = L.p[op + jmB]; bd3 = L.p[om + jmB]; bd4 = L.p[op + jpB];
+    }
+    ks_load<NZ, R, REAL>(A, L, o, cA, jmA, jpA, ka, w == 0);
+    ks_load<NZ, R, REAL>(B, L, o, cB, jmB, jpB, ka, w == 0);
+  }
+  if (lane == 0) {  // the halo column ny+1 of this plane (image of column ny: colour b's own, not touched by colour a)
+#pragma unroll
+    for (int r = 0; r < R; r++) xa[(ka + r - 1) * XS + nh] = L.p[o + (long long)(ka + r - 1) * L.RS + L.HO + nh];
+  }
+  if (live) ks_rhs<NZ, R, REAL>(A, pjm, pjp, d1, d2, d3, d4, ka, lane, sh, sa2, sbt);
+  __syncthreads();
+  if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, xa, XS);
+  __syncthreads();
+  if (live) {
+    ks_store<R>(L, o, cA, i, 2 * lane + 1, ka, lane, xa, XS, ph);
+    double qjm[R + 2], qjp[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; r++) {
+      const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+      qjm[r] = xa[(k - 1) * XS + lane]; qjp[r] = xa[(k - 1) * XS + lane + 1];
+    }
+    if (REAL && w == 0) {
+      // k=1 diagonals in a mirrored halo plane are images of colour a's new values (plane 0 of plane 1, plane nx+1 of plane nx)
+      if (mW) { bd1 = xa[lane + 1]; bd3 = xa[lane]; }
+      if (mE) { bd2 = xa[lane]; bd4 = xa[lane + 1]; }
+    }
+    ks_rhs<NZ, R, REAL>(B, qjm, qjp, bd1, bd2, bd3, bd4, ka, lane, sh, sa2, sbt);
+  }
+  __syncthreads();
+  if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, sh, WAVE);
+  __syncthreads();
+  if (live) ks_store<R>(L, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
+}
+
 extern "C" {
 
 // returns 1 when the pass was launched here (the level qualifies), 0 to let the row-by-row kernels take it
@@ -184,6 +365,19 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
   if (L->nz == 16) { if (nw_env == 4) KS_LAUNCH(16, 4) else KS_LAUNCH(16, 8) }
   if (nw_env == 4) KS_LAUNCH(8, 4) else KS_LAUNCH(8, 8)
 #undef KS_LAUNCH
+}
+
+// both colours of the planes i0, i0+2, ... of a four-colour sweep in one launch; returns 1 when launched (closed level, one column set per plane)
+int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, int real, Sides ph) {
+  static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr;
+  if (off || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || L->ny / 2 > WAVE) return 0;
+  if (L->nz != 16 && L->nz != 8) return 0;
+  dim3 grd(nplanes), blk(WAVE, 8);
+  if (L->nz == 16) { if (real) hipLaunchKernelGGL((k_relax_ks2<16, 8, true>), grd, blk, 0, st, *L, i0, nplanes, ph);
+                     else hipLaunchKernelGGL((k_relax_ks2<16, 8, false>), grd, blk, 0, st, *L, i0, nplanes, ph); }
+  else { if (real) hipLaunchKernelGGL((k_relax_ks2<8, 8, true>), grd, blk, 0, st, *L, i0, nplanes, ph);
+         else hipLaunchKernelGGL((k_relax_ks2<8, 8, false>), grd, blk, 0, st, *L, i0, nplanes, ph); }
+  return 1;
 }
 
 }  // extern "C"
