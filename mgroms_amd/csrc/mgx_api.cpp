@@ -105,6 +105,7 @@ struct Level {
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
   double *f2d_store[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *tab_store[2] = {nullptr, nullptr};  // m4,d4,m7,d7,h2,hi2,ze2 and cffw,csw (LevView)
+  double *zg_store[4] = {nullptr, nullptr, nullptr, nullptr};  // dx2,dy2,cffr,csr (LevView)
 };
 
 struct State {
@@ -746,7 +747,8 @@ int define_matrices() {
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
     L.v.m4 = L.f2d_store[0]; L.v.d4 = L.f2d_store[1]; L.v.m7 = L.f2d_store[2]; L.v.d7 = L.f2d_store[3];
     L.v.h2 = L.f2d_store[4]; L.v.hi2 = L.f2d_store[5]; L.v.ze2 = L.f2d_store[6]; L.v.cffw = L.tab_store[0]; L.v.csw = L.tab_store[1];
-    mgxs_zw_js(S.stream, &L.g, &L.v, S.hlim, S.theta_b, S.theta_s); S.n_launch += 2;
+    L.v.dx2 = L.zg_store[0]; L.v.dy2 = L.zg_store[1]; L.v.cffr = L.zg_store[2]; L.v.csr = L.zg_store[3];
+    mgxs_zw_js(S.stream, &L.g, &L.v, S.hlim, S.theta_b, S.theta_s); S.n_launch += 3;
     if (S.no_mf || S.par.bmask) { L.v.zy = L.v.zx = nullptr; L.v.m4 = nullptr; }  // masked coefficients are not rebuilt from the slopes
   }
   CHK(sync_stream());
@@ -1068,6 +1070,9 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int q = 0; q < 7; q++) CHK(dmalloc(&L.f2d_store[q], (size_t)(L.nx + 2) * L.v.RS));
     for (int q = 0; q < 2; q++) CHK(dmalloc(&L.tab_store[q], (size_t)L.nz + 1));
     L.v.m4 = L.v.d4 = L.v.m7 = L.v.d7 = L.v.h2 = L.v.hi2 = L.v.ze2 = nullptr; L.v.cffw = L.v.csw = nullptr;
+    for (int q = 0; q < 2; q++) CHK(dmalloc(&L.zg_store[q], (size_t)(L.nx + 2) * L.v.RS));
+    for (int q = 2; q < 4; q++) CHK(dmalloc(&L.zg_store[q], (size_t)L.nz + 1));
+    L.v.dx2 = L.v.dy2 = nullptr; L.v.cffr = L.v.csr = nullptr;
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
     CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));

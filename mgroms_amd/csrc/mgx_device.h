@@ -52,6 +52,17 @@ static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3
 #ifndef MGX_ZW
 #define MGX_ZW 1
 #endif
+// MGX_ZG: with MGX_ZW, the column's own slopes zy, zx are rebuilt in the kernel as well (relax_col_mf); -DMGX_ZG=0 streams them (A/B)
+#ifndef MGX_ZG
+#define MGX_ZG 1
+#endif
+// A quotient whose divisor is a per-column constant: the divisor's reciprocal is refined once with the two Newton steps of the hardware
+// division sequence (v_rcp_f64, fma, fma, fma, fma) and each quotient then takes the sequence's last three operations (mul, fma, fma) --
+// the same operations on the same values as `/` while no operand needs v_div_scale's rescaling (depths, metric factors: normal range),
+// hence the same bits, at 3 instructions instead of ~11 per division.
+#define RCP_REF(b) ({ const double b_ = (b); double r_ = __builtin_amdgcn_rcp(b_); double e_ = __builtin_fma(-b_, r_, 1.0); r_ = __builtin_fma(r_, e_, r_); \
+                      e_ = __builtin_fma(-b_, r_, 1.0); __builtin_fma(r_, e_, r_); })
+#define DIVC(a, b, rb) ({ const double a_ = (a); const double q_ = a_ * (rb); const double e_ = __builtin_fma(-(b), q_, a_); __builtin_fma(e_, (rb), q_); })
 #if MGX_PAIR
 #define LD_PAIR(ptr, A, B) { double2 t2_; __builtin_memcpy(&t2_, (ptr), 16); A = t2_.x; B = t2_.y; }
 #else

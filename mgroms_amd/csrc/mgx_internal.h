@@ -26,6 +26,11 @@ struct LevView {
   // m7 = dy(j,i)+dy(j,i-1), d7 = hlf*(dx(j,i)+dx(j,i-1)).  nullptr = stored slots.
   double *m4, *d4, *m7, *d7, *h2, *hi2, *ze2;
   const double *cffw, *csw;
+  // The column's OWN slopes zy, zx rebuilt in the kernel too (ZG, mgx_relax.hip): zr of the four face neighbours from the same formula at
+  // the rho points (tables cffr = hlim*sc_r, csr = Cs_r of nz entries, mg_zr_zw.f90:108-122), then the reference's slope expression
+  // with the column's dx, dy (dx2, dy2: JS 2-D order).  nullptr = streamed.
+  double *dx2, *dy2;
+  const double *cffr, *csr;
 };
 
 __host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }

@@ -254,7 +254,12 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
 // bit-identical values (the halo columns too: h and zeta carry the same mirror / exchange rules as zw), FOUR streams less, at seven
 // flops per depth and four fp64 divisions per row under the loads.  Rows 1 and nz of slots 4 / 7 have other formulas
 // (:361-372,:577-590): they read the stored slots.
-template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false, bool ZW = false>
+// ZG (with ZW): the column's OWN slopes are not streamed either.  zy(k,j,i) = ((hlf*(zr(k,j+1,i)-zr(k,j-1,i)))/dy(j,i))*dx(j,i), zx likewise in
+// i (mg_define_matrix.f90:358,398), need zr of the four face neighbours, whose h, hinv, zeta ZW holds already: zr = z0*h*hinv +
+// zeta*(1.+z0*hinv), z0 = cffr(k)+csr(k)*h (mg_zr_zw.f90:112-122) -- four depths, two slopes per row, TWO streams less (the slopes of the
+// face neighbours, which would need zr of the second ring, stay streamed).  All six divisors of the generated coefficients (dy, dx of the
+// column; the four of slots 4 / 7) are per-column constants: DIVC (mgx_device.h).
+template <int NZ, bool REAL, bool SNAP, int D, bool ST, bool GL = false, bool ZW = false, bool ZG = false>
 __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, const int jh, const int jodd, const Sides ph, double *__restrict__ gl = nullptr) {
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
@@ -271,7 +276,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   constexpr int RN = D + 2;  // rows k .. k+1+D are live at iteration k (row k is still read after the look-ahead load is issued)
   constexpr int RO = D + 2;  // own rows are needed one row early (zy(k+1), zx(k+1))
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
-  double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
+  double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[ZG ? 1 : RO], o_zx[ZG ? 1 : RO];
   double x[NZ], g[GL ? 1 : NZ];
   double zw0[5], zw1[5];  // ZW: generated zw of the column and of its j-1, j+1, i-1, i+1 neighbours, rows k and k+1
   const int lane = threadIdx.x;
@@ -292,14 +297,17 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); \
     if (!ZW) { o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); } \
     if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
-    o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
+    if (!ZG) { o_zy[ZG ? 0 : s_] = ld_stream<ST>(zy + ko_); o_zx[ZG ? 0 : s_] = ld_stream<ST>(zx + ko_); }       \
   }
   // PV: the diagonal of the first and the last row is read (two rows of the stored slot 1), the interior rows rebuild it
   double dg1 = 0, dgn = 0;
   if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
   // ZW: stored slots 4 and 7 of the first and the last row, and the per-column factors of the interior formula
   double hh[5], hv[5], hz[5];  // h, hinv, zeta of the five columns
-  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw;
+  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw, *__restrict__ cffr = L.cffr, *__restrict__ csr = L.csr;
+  double r4c = 0, r4p = 0, r7c = 0, r7p = 0;                 // refined reciprocals of d4c, d4p, d7c, d7p
+  double gdx = 1, gdy = 1, rdx = 0, rdy = 0;                 // ZG: dx, dy of the column and their reciprocals
+  const double hlf = 0.5;
   double a4_1 = 0, a4j_1 = 0, a7_1 = 0, a7i_1 = 0, a4_n = 0, a4j_n = 0, a7_n = 0, a7i_n = 0, m4c = 0, m4p = 0, d4c = 1, d4p = 1, m7c = 0, m7p = 0, d7c = 1, d7p = 1;
   if (ZW) {
     const long long rn = (long long)(NZ - 1) * RS;
@@ -311,7 +319,13 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     const long long cq[5] = {q2 + c, q2 + jm, q2 + jp, q2 - RS + c, q2 + RS + c};  // the column, j-1, j+1, i-1, i+1
 #pragma unroll
     for (int q = 0; q < 5; q++) { hh[q] = L.h2[cq[q]]; hv[q] = L.hi2[cq[q]]; hz[q] = L.ze2[cq[q]]; }
+    r4c = RCP_REF(d4c); r4p = RCP_REF(d4p); r7c = RCP_REF(d7c); r7p = RCP_REF(d7p);
+    if (ZG) { gdx = L.dx2[q2 + c]; gdy = L.dy2[q2 + c]; rdx = RCP_REF(gdx); rdy = RCP_REF(gdy); }
   }
+  // zr(kk, column q) by its generating formula (mg_zr_zw.f90:112-122); own slopes of row kk from the four face neighbours
+#define ZR_GEN(kk, q) ({ const double z0_ = cffr[(kk)-1] + csr[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
+#define OWN_SLOPES(kk, ZY, ZX) { const double zn1_ = ZR_GEN(kk, 1), zn2_ = ZR_GEN(kk, 2), zn3_ = ZR_GEN(kk, 3), zn4_ = ZR_GEN(kk, 4); \
+    ZY = DIVC(hlf * (zn2_ - zn1_), gdy, rdy) * gdx; ZX = DIVC(hlf * (zn4_ - zn3_), gdx, rdx) * gdy; }
   // zw(kk, column q) by its generating formula (mg_zr_zw.f90:140-145)
 #define ZW_GEN(kk, q) ({ const double z0_ = cffw[(kk)-1] + csw[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
@@ -329,7 +343,9 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
   // three-row windows (k-1, k, k+1) of the neighbour columns' p and of the own slopes
   double pjm_m = 0, pjm_0 = r_pjm[1 % RN], pjm_p = 0, pim_m = 0, pim_0 = r_pim[1 % RN], pim_p = 0;
   double pjp_m = 0, pjp_0 = r_pjp[1 % RN], pjp_p = 0, pip_m = 0, pip_0 = r_pip[1 % RN], pip_p = 0;
-  double zy_m = 0, zy_0 = o_zy[1 % RO], zy_p = 0, zx_m = 0, zx_0 = o_zx[1 % RO], zx_p = 0;
+  double zy_m = 0, zy_0 = 0, zy_p = 0, zx_m = 0, zx_0 = 0, zx_p = 0;
+  if (ZG) OWN_SLOPES(1, zy_0, zx_0)
+  else { zy_0 = o_zy[ZG ? 0 : 1 % RO]; zx_0 = o_zx[ZG ? 0 : 1 % RO]; }
   double xv = 0.0, betp = 0.0;
 #pragma unroll
   for (int k = 1; k <= NZ; k++) {
@@ -338,7 +354,8 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     if (k < NZ) {
       const int s1 = (k + 1) % RN, t1 = (k + 1) % RO;
       pjm_p = r_pjm[s1]; pim_p = r_pim[s1]; pjp_p = r_pjp[s1]; pip_p = r_pip[s1];
-      zy_p = o_zy[t1]; zx_p = o_zx[t1];
+      if (ZG) OWN_SLOPES(k + 1, zy_p, zx_p)
+      else { zy_p = o_zy[ZG ? 0 : t1]; zx_p = o_zx[ZG ? 0 : t1]; }
     }
     const int s = k % RO, n = k % RN;
     const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n];
@@ -358,10 +375,10 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 #pragma unroll
       for (int q = 0; q < 5; q++) zw1[q] = ZW_GEN(k + 1, q);
       const double wo0 = zw0[0], wop1 = zw1[0];
-      a4o = (qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c) / d4c;
-      a4jp = (qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p) / d4p;
-      a7o = (qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c) / d7c;
-      a7ip = (qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p) / d7p;
+      a4o = DIVC(qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c, d4c, r4c);
+      a4jp = DIVC(qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p, d4p, r4p);
+      a7o = DIVC(qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c, d7c, r7c);
+      a7ip = DIVC(qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p, d7p, r7p);
 #pragma unroll
       for (int q = 0; q < 5; q++) zw0[q] = zw1[q];
     }
@@ -439,6 +456,8 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
 #undef NB_LOAD
 #undef OW_LOAD
 #undef ZW_GEN
+#undef ZR_GEN
+#undef OWN_SLOPES
 }
 
 template <int NZ, bool REAL, bool SNAP, int D, bool MF, bool ST>
@@ -465,8 +484,8 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   constexpr bool ZW = MF && NZ >= 32 && MGX_ZW;
   if (GL) {
     extern __shared__ double g_lds[];  // blockDim.y waves x NZ rows x 64 lanes
-    relax_col_mf<NZ, REAL, SNAP, D, ST, GL, ZW>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
-  } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST, false, ZW>(L, i, jh, jodd, ph);
+    relax_col_mf<NZ, REAL, SNAP, D, ST, GL, ZW, ZW && MGX_ZG>(L, i, jh, jodd, ph, g_lds + (size_t)threadIdx.y * NZ * WAVE);
+  } else if (MF) relax_col_mf<NZ, REAL, SNAP, D, ST, false, ZW, ZW && MGX_ZG>(L, i, jh, jodd, ph);
   else relax_col_nz<NZ, REAL, SNAP, D>(L, i, jh, jodd, ph);
 }
 

@@ -28,12 +28,15 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
   constexpr int RN = D + 2;  // rows k .. k+1+D are live at iteration k (row k is still read after the look-ahead load is issued)
   constexpr int RO = D + 2;  // own rows are needed one row early (zy(k+1), zx(k+1))
   double r_pjm[RN], r_pim[RN], r_pjp[RN], r_pip[RN], r_zyjm[RN], r_zyjp[RN], r_zxim[RN], r_zxip[RN], r_a4[RN], r_a7[RN];
-  double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[RO], o_zx[RO];
+  constexpr bool ZW = MGX_ZW;  // slots 4 and 7 of the interior rows from regenerated interface depths, see relax_col_mf (mgx_relax.hip)
+  constexpr bool ZG = ZW && MGX_ZG;  // and the column's own slopes from regenerated zr of the face neighbours (same place)
+  double o_b[RO], o_a2[RO], o_a4[RO], o_a7[RO], o_bet[RO], o_zy[ZG ? 1 : RO], o_zx[ZG ? 1 : RO];
   constexpr int UP = NZ - LOW;
   double x[UP], g[UP];
-  constexpr bool ZW = MGX_ZW;  // slots 4 and 7 of the interior rows from regenerated interface depths, see relax_col_mf (mgx_relax.hip)
   double zw0[5], zw1[5], hh[5], hv[5], hz[5];
-  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw;
+  const double *__restrict__ cffw = L.cffw, *__restrict__ csw = L.csw, *__restrict__ cffr = L.cffr, *__restrict__ csr = L.csr;
+  double r4c = 0, r4p = 0, r7c = 0, r7p = 0, gdx = 1, gdy = 1, rdx = 0, rdy = 0;  // reciprocals of the constant divisors (DIVC, mgx_device.h)
+  const double hlf = 0.5;
 
 #define NB_LOAD(q)                                                               \
   if ((q) <= NZ) {                                                               \
@@ -50,7 +53,7 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     o_b[s_] = ld_stream<ST>(b + ko_); o_a2[s_] = ld_stream<ST>(a2 + ko_); \
     if (!ZW) { o_a4[s_] = ld_stream<ST>(a4 + ko_); o_a7[s_] = ld_stream<ST>(a7 + ko_); } \
     if (!MGX_PV) o_bet[s_] = ld_stream<ST>(bet + ko_); \
-    o_zy[s_] = ld_stream<ST>(zy + ko_); o_zx[s_] = ld_stream<ST>(zx + ko_);                                      \
+    if (!ZG) { o_zy[ZG ? 0 : s_] = ld_stream<ST>(zy + ko_); o_zx[ZG ? 0 : s_] = ld_stream<ST>(zx + ko_); }       \
   }
   double dg1 = 0, dgn = 0;
   if (MGX_PV) { dg1 = a1[o + c]; dgn = a1[o + (long long)(NZ - 1) * RS + c]; }
@@ -65,7 +68,12 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     const long long cq[5] = {q2 + c, q2 + jm, q2 + jp, q2 - RS + c, q2 + RS + c};
 #pragma unroll
     for (int q = 0; q < 5; q++) { hh[q] = L.h2[cq[q]]; hv[q] = L.hi2[cq[q]]; hz[q] = L.ze2[cq[q]]; }
+    r4c = RCP_REF(d4c); r4p = RCP_REF(d4p); r7c = RCP_REF(d7c); r7p = RCP_REF(d7p);
+    if (ZG) { gdx = L.dx2[q2 + c]; gdy = L.dy2[q2 + c]; rdx = RCP_REF(gdx); rdy = RCP_REF(gdy); }
   }
+#define ZR_GEN(kk, q) ({ const double z0_ = cffr[(kk)-1] + csr[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
+#define OWN_SLOPES(kk, ZY, ZX) { const double zn1_ = ZR_GEN(kk, 1), zn2_ = ZR_GEN(kk, 2), zn3_ = ZR_GEN(kk, 3), zn4_ = ZR_GEN(kk, 4); \
+    ZY = DIVC(hlf * (zn2_ - zn1_), gdy, rdy) * gdx; ZX = DIVC(hlf * (zn4_ - zn3_), gdx, rdx) * gdy; }
 #define ZW_GEN(kk, q) ({ const double z0_ = cffw[(kk)-1] + csw[(kk)-1] * hh[q]; z0_ * hh[q] * hv[q] + hz[q] * (1. + z0_ * hv[q]); })
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
   if (REAL) {
@@ -82,7 +90,9 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
   // three-row windows (k-1, k, k+1) of the neighbour columns' p and of the own slopes
   double pjm_m = 0, pjm_0 = r_pjm[1 % RN], pjm_p = 0, pim_m = 0, pim_0 = r_pim[1 % RN], pim_p = 0;
   double pjp_m = 0, pjp_0 = r_pjp[1 % RN], pjp_p = 0, pip_m = 0, pip_0 = r_pip[1 % RN], pip_p = 0;
-  double zy_m = 0, zy_0 = o_zy[1 % RO], zy_p = 0, zx_m = 0, zx_0 = o_zx[1 % RO], zx_p = 0;
+  double zy_m = 0, zy_0 = 0, zy_p = 0, zx_m = 0, zx_0 = 0, zx_p = 0;
+  if (ZG) OWN_SLOPES(1, zy_0, zx_0)
+  else { zy_0 = o_zy[ZG ? 0 : 1 % RO]; zx_0 = o_zx[ZG ? 0 : 1 % RO]; }
   double xv = 0.0, betp = 0.0;
   const int lane = threadIdx.x;
 #define FWD_ROW(k)                                                        \
@@ -92,7 +102,8 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
     if (k < NZ) { \
       const int s1 = (k + 1) % RN, t1 = (k + 1) % RO; \
       pjm_p = r_pjm[s1]; pim_p = r_pim[s1]; pjp_p = r_pjp[s1]; pip_p = r_pip[s1]; \
-      zy_p = o_zy[t1]; zx_p = o_zx[t1]; \
+      if (ZG) OWN_SLOPES(k + 1, zy_p, zx_p) \
+      else { zy_p = o_zy[ZG ? 0 : t1]; zx_p = o_zx[ZG ? 0 : t1]; } \
     } \
     const int s = k % RO, n = k % RN; \
     const double zyjm = r_zyjm[n], zyjp = r_zyjp[n], zxim = r_zxim[n], zxip = r_zxip[n]; \
@@ -106,10 +117,10 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
       if (k == 2) { _Pragma("unroll") for (int q = 0; q < 5; q++) zw0[q] = ZW_GEN(2, q); } \
       _Pragma("unroll") for (int q = 0; q < 5; q++) zw1[q] = ZW_GEN(k + 1, q); \
       const double wo0 = zw0[0], wop1 = zw1[0]; \
-      a4o = (qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c) / d4c; \
-      a4jp = (qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p) / d4p; \
-      a7o = (qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c) / d7c; \
-      a7ip = (qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p) / d7p; \
+      a4o = DIVC(qrt * (wop1 - wo0 + zw1[1] - zw0[1]) * m4c, d4c, r4c); \
+      a4jp = DIVC(qrt * (zw1[2] - zw0[2] + wop1 - wo0) * m4p, d4p, r4p); \
+      a7o = DIVC(qrt * (wop1 - wo0 + zw1[3] - zw0[3]) * m7c, d7c, r7c); \
+      a7ip = DIVC(qrt * (zw1[4] - zw0[4] + wop1 - wo0) * m7p, d7p, r7p); \
       _Pragma("unroll") for (int q = 0; q < 5; q++) zw0[q] = zw1[q]; \
     } \
     double betk; \
@@ -156,6 +167,8 @@ __device__ __forceinline__ void relax_col_mf_tall(const LevView &L, const int i,
   for (int k = LOW + 1; k <= NZ; k++) FWD_ROW(k)
 #undef FWD_ROW
 #undef ZW_GEN
+#undef ZR_GEN
+#undef OWN_SLOPES
 #pragma unroll
   for (int k = UP - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
 

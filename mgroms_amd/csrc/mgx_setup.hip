@@ -290,6 +290,20 @@ __global__ void k_zw_js(GeoView G, LevView L, double hlim) {
   L.h2[o2] = h;
   L.hi2[o2] = one / (h + hlim);   // hinv of mg_zr_zw.f90:106, the same expression as k_zr_zw
   L.ze2[o2] = A2(G.zeta, j, i);
+  if (L.dx2) { L.dx2[o2] = DX(j, i); L.dy2[o2] = DY(j, i); }
+}
+// sigma tables of the rho-points, k = 1..nz: cffr(k) = hlim*sc_r, csr(k) = Cs_r (mg_zr_zw.f90:108-122), same expressions as k_zr_zw
+__global__ void k_sigma_tables_r(int nz, double hlim, double theta_b, double theta_s, double *cffr, double *csr) {
+  const int k = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nz) return;
+  const double one = 1.0, hlf = 0.5, nul = 0.0;
+  const double cff = one / (double)nz;
+  double csrf, cs_r;
+  const double sc_r = cff * ((double)(k - nz) - hlf);
+  if (theta_s > nul) csrf = (one - cosh(theta_s * sc_r)) / (cosh(theta_s) - one); else csrf = -(sc_r * sc_r);
+  if (theta_b > nul) cs_r = (exp(theta_b * csrf) - one) / (one - exp(-theta_b)); else cs_r = csrf;
+  cffr[k - 1] = hlim * sc_r;
+  csr[k - 1] = cs_r;
 }
 // sigma tables of the w-points, k = 1..nz+1: cffw(k) = hlim*sc_w, csw(k) = Cs_w (mg_zr_zw.f90:124-141), same expressions as k_zr_zw
 __global__ void k_sigma_tables(int nz, double hlim, double theta_b, double theta_s, double *cffw, double *csw) {
@@ -357,6 +371,7 @@ void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLau
 void mgxs_zw_js(hipStream_t st, const GeoView *G, const LevView *L, double hlim, double theta_b, double theta_s) {
   hipLaunchKernelGGL(k_zw_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L, hlim);
   hipLaunchKernelGGL(k_sigma_tables, dim3((G->nz + 1 + 63) / 64), dim3(64), 0, st, G->nz, hlim, theta_b, theta_s, (double *)L->cffw, (double *)L->csw);
+  if (L->cffr) hipLaunchKernelGGL(k_sigma_tables_r, dim3((G->nz + 63) / 64), dim3(64), 0, st, G->nz, hlim, theta_b, theta_s, (double *)L->cffr, (double *)L->csr);
 }
 void mgxs_pivots(hipStream_t st, const LevView *L) { hipLaunchKernelGGL(k_pivots, cgrid(L->ny, L->nx), CBLK, 0, st, *L); }
 }
