@@ -170,6 +170,22 @@ def test_config2_fc_256x256x32_bitwise(mg):
 
 
 # ---- BASELINE config 3: seamount 512x512x64, four-colour, one V-cycle bit for bit ---------------------------------------
+@pytest.mark.parametrize("dims,geom", [((96, 48, 16), "seamount"), ((48, 96, 32), "rndtopo"), ((64, 128, 8), "seamount"), ((128, 64, 16), "rndtopo")])
+def test_fc_ragged_shapes_bitwise(mg, dims, geom):
+    # shapes whose levels exercise the partly filled waves of the mid- and coarse-level kernels (a plane of 24 / 48 / 64 columns per
+    # colour for the colour-pair kernel, 72- and 18-block levels for the register-resident coarse kernels, runs of the prolongation
+    # that end inside a wave): three F-cycle iterations, every level's p bit for bit
+    nx, ny, nz = dims
+    _gpu(mg, nx, ny, nz, geom, relax_method="FC")
+    o = _oracle(nx, ny, nz, geom=geom, relax_method="FC")
+    assert mg.nlevs() == o.nlevs
+    n, hist = mg.solve_p(1e-30, 3)
+    no, ho, _ = o.solve_p(1e-30, 3)
+    assert n == no == 3 and _hist_close(hist, ho)
+    for lev in range(1, o.nlevs + 1):
+        assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
+
+
 def test_config3_vcycle_512x512x64_bitwise(mg, golden):
     _gpu(mg, 512, 512, 64, relax_method="FC")
     b_gpu = mg.grid(1).b
