@@ -81,7 +81,7 @@ void mgx_clean(void);
 /* mg_solvers.f90:17-101 solve_p(tol,maxite).  *nite = iterations done, *res = last ||r||/||b||,
  * hist (may be NULL, else >= maxite+1 doubles) = normalised residual after each iteration, hist[0] = initial. */
 int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist);
-/* mg_solvers.f90:104-126.  Fcycle restricts grid(1)%r on its way down: call mgx_compute_residual(1) first, as solve_p does
+/* mg_solvers.f90:104-126.  Fcycle restricts grid(1)%r on its way down: call mgx_residual for level 1 first, as solve_p does
  * (:50); the r a previous cycle's coarse2fine would have left there is not kept unless option "keep_r" is set. */
 int mgx_fcycle(void);
 int mgx_vcycle(int lev);                  /* mg_solvers.f90:129-151 */
