@@ -271,6 +271,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname + " (level-1 colour pass)",
                          "algorithmic_bytes_per_launch": launch_bytes,
+                         "traffic_note": "counter traffic below the algorithmic bytes: SURVEY 8(d)'s 88 B/cell counts 11 streamed arrays; the pass "
+                                         "rebuilds the pivots, slots 4/7 (from regenerated zw) and its own slopes in registers and streams 7 (DESIGN.md section 4)",
                          "launch_ms": sweep_ms / ncol, "sweep_ms": sweep_ms},
             "residual_kernel": {"ms": resid_ms, "GBs": 88 * cells / (resid_ms * 1e-3) / 1e9},
             "fcycle_iterations_per_sec": fc_rate,
