@@ -6,6 +6,7 @@ set -e
 OUT=$1; NX=$2; NY=$3; NZ=$4; NS=$5
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
+OUT=$(cd "$OUT" && pwd)   # absolute: the profiler runs from /tmp
 cd /tmp; export TMPDIR=/tmp
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29561 WORLD_SIZE=2
 for r in 0 1; do
