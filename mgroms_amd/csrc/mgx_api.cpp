@@ -38,7 +38,7 @@ void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *
 void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
-void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int);
+void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int, int);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, double *const *, unsigned long long *const *,
@@ -566,14 +566,16 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
 
 // mg_intergrids.f90:167-228.  keep_r: also leave the interpolated correction in the fine r, as the reference does (the C-ABI operator
 // and exact_halos = 1); the cycles do not -- nothing reads it before compute_residual overwrites it.
-int coarse2fine(int lev, bool keep_r = true) {
+// skip1: a four-colour relax(lev, n >= 1) follows immediately -- its first colour overwrites the (i odd, j odd) columns without reading
+// them, so the prolongation leaves them alone (never together with keep_r).
+int coarse2fine(int lev, bool keep_r = true, bool skip1 = false) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0};
   if (!C.gather) {
-    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf, keep_r); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf, keep_r, skip1 && !keep_r); S.n_launch++;
   } else {
     mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
-    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf, keep_r); S.n_launch++;
+    mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf, keep_r, skip1 && !keep_r); S.n_launch++;
   }
   if (S.exact_halos && keep_r) CHK(fill_halo_js(F, F.v.r, true)); else F.r_halo_stale = true;
   // p = p + r over the whole array: the interior was updated by the kernel; the halo of p + halo of r
@@ -590,7 +592,7 @@ int vcycle(int lev1) {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_post >= 1));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -604,7 +606,7 @@ int vcycle2(int lev1, int lev2) {
   }
   CHK(relax(lev2, S.par.ns_coarsest));
   for (int lev = lev2 - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_post >= 1));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -618,7 +620,7 @@ int fcycle() {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_pre >= 1));
     CHK(vcycle(lev));
   }
   return 0;

@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) void k_coarse2fine(LevView F, LevView C, const
 // p of the next coarse level are requested before the current level is stored (without that look-ahead the run is a chain of
 // load -> store round trips and loses: 106 us; with it 71 us against 83 us of k_coarse2fine at 512x512x64, WR = false).
 // Same expressions in the same order as above (mg_intergrids.f90:392-446): bit-identical.
-template <bool WR>
+// SK: the fine columns (i odd, j odd) are left alone -- the first colour of the four-colour sweep that follows overwrites them without
+// reading them (a line solve reads only the other columns; mg_relax.f90:212-230), which is a quarter of this kernel's traffic.  Except
+// next to a physical south / west boundary: there the column reads its own old value through the mirrored halo cell (p(0) = p(1)),
+// so columns j = 1 and i = 1 are updated (and mirrored) as usual.
+template <bool WR, bool SK>
 __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, const double *__restrict__ xc, Sides ph, int stream, int KC) {
   const int lane = threadIdx.x;
   const int j2 = 1 + blockIdx.x * WAVE + lane;
@@ -377,13 +381,18 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
   if (live) {                                                                                                       \
     _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                              \
       const long long ro_ = (long long)(2 * (kk) - 2 + h_) * F.RS;                                                  \
-      v[4 * h_ + 0] = ld_rt(pf + o0 + ro_ + po, stream); v[4 * h_ + 1] = ld_rt(pf + o0 + ro_ + pe, stream);         \
+      if (!SK || edge0) v[4 * h_ + 0] = ld_rt(pf + o0 + ro_ + po, stream);                                          \
+      v[4 * h_ + 1] = ld_rt(pf + o0 + ro_ + pe, stream);                                                            \
       v[4 * h_ + 2] = ld_rt(pf + o1 + ro_ + po, stream); v[4 * h_ + 3] = ld_rt(pf + o1 + ro_ + pe, stream);         \
     }                                                                                                               \
   }
-#define PUT(k, OO, PP, val) { const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO + ro_ + PP; const double v_ = (val), w_ = pc[4 * half + 2 * (OO == o1) + (PP == pe)] + v_; if (WR) st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream); \
-    const int jf_ = (PP == po) ? 2 * j2 - 1 : 2 * j2, if_ = (OO == o0) ? i : i + 1; \
-    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP, w_, ph); }
+  // fine cell Q of the 2x2 block: bit 1 = plane i+1, bit 0 = column j+1 (Q = 0 is the first colour's column)
+#define PUT(k, Q, val) if (!(SK && (Q) == 0) || edge0) { const long long OO_ = ((Q) & 2) ? o1 : o0; const int PP_ = ((Q) & 1) ? pe : po;                      \
+    const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO_ + ro_ + PP_; const double v_ = (val), w_ = pc[4 * half + (Q)] + v_;                     \
+    if (WR) st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream);                                                                                    \
+    const int jf_ = ((Q) & 1) ? 2 * j2 : 2 * j2 - 1, if_ = ((Q) & 2) ? i + 1 : i;                                                                      \
+    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP_, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP_, w_, ph); }
+  const bool edge0 = (ph.S && j2 == 1) || (ph.W && i2 == 1);  // SK: the (i odd, j odd) column of this lane is read through a mirror
   const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
   double pc[8], pa[8], pb[8];  // fine p of the level in work and of the next one (two levels ahead measured slower: 76 vs 71 us)
   double lo[9], x[9], hi[9];  // coarse levels k2-1, k2, k2+1
@@ -406,22 +415,22 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
       _Pragma("unroll") for (int half = 0; half < 2; half++) {                                                      \
         const int k = 2 * k2 - 1 + half;  /* fine level */                                                          \
         if (k == 1) {                      /* bottom level: bilinear (mg_intergrids.f90:392-405) */                  \
-          PUT(1, o0, po, +a * x00 + c * xmm + b * xm0 + b * x0m);                                                   \
-          PUT(1, o0, pe, +a * x00 + c * xpm + b * xp0 + b * x0m);                                                   \
-          PUT(1, o1, po, +a * x00 + c * xmp + b * xm0 + b * x0p);                                                   \
-          PUT(1, o1, pe, +a * x00 + c * xpp + b * xp0 + b * x0p);                                                   \
+          PUT(1, 0, +a * x00 + c * xmm + b * xm0 + b * x0m);                                                   \
+          PUT(1, 1, +a * x00 + c * xpm + b * xp0 + b * x0m);                                                   \
+          PUT(1, 2, +a * x00 + c * xmp + b * xm0 + b * x0p);                                                   \
+          PUT(1, 3, +a * x00 + c * xpp + b * xp0 + b * x0p);                                                   \
         } else if (k == 2 * nz) {          /* top level: 1/2 bilinear (:434-446) */                                  \
-          PUT(k, o0, po, 0.5 * (a * x00 + c * xmm + b * xm0 + b * x0m));                                            \
-          PUT(k, o0, pe, 0.5 * (a * x00 + c * xpm + b * xp0 + b * x0m));                                            \
-          PUT(k, o1, po, 0.5 * (a * x00 + c * xmp + b * xm0 + b * x0p));                                            \
-          PUT(k, o1, pe, 0.5 * (a * x00 + c * xpp + b * xp0 + b * x0p));                                            \
+          PUT(k, 0, 0.5 * (a * x00 + c * xmm + b * xm0 + b * x0m));                                            \
+          PUT(k, 1, 0.5 * (a * x00 + c * xpm + b * xp0 + b * x0m));                                            \
+          PUT(k, 2, 0.5 * (a * x00 + c * xmp + b * xm0 + b * x0p));                                            \
+          PUT(k, 3, 0.5 * (a * x00 + c * xpp + b * xp0 + b * x0p));                                            \
         } else {                           /* interior: tri-linear, kp = k2-1 for odd k, k2+1 for even k (:407-432) */ \
           const double *__restrict__ y = half ? hi : lo;                                                            \
           const double ymm = y[0], y0m = y[1], ypm = y[2], ym0 = y[3], y00 = y[4], yp0 = y[5], ymp = y[6], y0p = y[7], ypp = y[8]; \
-          PUT(k, o0, po, +d * x00 + f * xmm + e * xm0 + e * x0m + e * y00 + g * ymm + f * ym0 + f * y0m);           \
-          PUT(k, o0, pe, +d * x00 + f * xpm + e * xp0 + e * x0m + e * y00 + g * ypm + f * yp0 + f * y0m);           \
-          PUT(k, o1, po, +d * x00 + f * xmp + e * xm0 + e * x0p + e * y00 + g * ymp + f * ym0 + f * y0p);           \
-          PUT(k, o1, pe, +d * x00 + f * xpp + e * xp0 + e * x0p + e * y00 + g * ypp + f * yp0 + f * y0p);           \
+          PUT(k, 0, +d * x00 + f * xmm + e * xm0 + e * x0m + e * y00 + g * ymm + f * ym0 + f * y0m);           \
+          PUT(k, 1, +d * x00 + f * xpm + e * xp0 + e * x0m + e * y00 + g * ypm + f * yp0 + f * y0m);           \
+          PUT(k, 2, +d * x00 + f * xmp + e * xm0 + e * x0p + e * y00 + g * ymp + f * ym0 + f * y0p);           \
+          PUT(k, 3, +d * x00 + f * xpp + e * xp0 + e * x0p + e * y00 + g * ypp + f * yp0 + f * y0p);           \
         }                                                                                                           \
       }                                                                                                             \
     }                                                                                                               \
@@ -737,7 +746,8 @@ void mgxk_dot(hipStream_t st, const LevView *L, const double *a, const double *b
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {
   hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero);
 }
-void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r) {
+// skip1: the caller guarantees that a four-colour relax of the fine level follows (cycles only; see k_coarse2fine_run, SK)
+void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r, int skip1) {
   static const bool norun = getenv("MGX_C2F_OLD") != nullptr;
   if (linear && !norun) {
     // runs of KC coarse levels per lane: long enough to amortise the three-level window, short enough to keep >= ~2 waves per SIMD
@@ -750,8 +760,10 @@ void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const 
     dim3 blk(WAVE, byr), grd((C->ny + WAVE - 1) / WAVE, (nrun + byr - 1) / byr, C->nx);
     static const int ntenv = getenv("MGX_C2F_NT") ? atoi(getenv("MGX_C2F_NT")) : -1;  // A/B: force the streaming hints on / off
     const int nt = ntenv >= 0 ? ntenv : level_streams(F);
-    if (keep_r) hipLaunchKernelGGL((k_coarse2fine_run<true>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
-    else hipLaunchKernelGGL((k_coarse2fine_run<false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    static const bool nosk = getenv("MGX_C2F_NOSKIP") != nullptr;
+    if (keep_r) hipLaunchKernelGGL((k_coarse2fine_run<true, false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    else if (skip1 && !nosk && !(F->nx & 1) && !(F->ny & 1)) hipLaunchKernelGGL((k_coarse2fine_run<false, true>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    else hipLaunchKernelGGL((k_coarse2fine_run<false, false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
     return;
   }
   const int by = C->nz >= 4 ? 4 : C->nz;
