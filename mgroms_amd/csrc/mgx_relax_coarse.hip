@@ -7,6 +7,10 @@
 // single-wave barrier only.  The level above it (32x32x4, 1024 columns) runs the same way on four waves of one workgroup
 // (k_relax_small re-read every operand through L2 there: 4.5 us per pass).  Everything that does not change between passes -- b, the own slots and pivots, the slots of the
 // j+1 / i+1 neighbours, gam -- sits in registers (4 columns x NZ rows x 16 values); p lives in LDS with its mirrored halo.
+// The level is closed (every side physical), so every halo cell is the image of an interior cell at all times (mg_mpi_exchange.f90:509-537,
+// corners :552-597): p sits in LDS WITHOUT a halo and a column reads its j-1 / j+1 / i-1 / i+1 neighbours and the four k=1 diagonals
+// through indices clamped to the interior -- no mirror stores, no branches in a pass (they were a third of its instructions); the halo of
+// the global array is rebuilt once, when p is written back.
 // Same expressions in the same order as relax_col_nz / k_relax_reg: bit-identical.
 #include <cstdlib>
 
@@ -15,13 +19,13 @@
 template <int NZ, bool REAL, int NT>
 __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph) {
   extern __shared__ double ldsw[];
-  const int nx = G.nx, ny = G.ny, W = ny + 2, PL = (nx + 2) * W;  // P[k][i][j]
+  const int nx = G.nx, ny = G.ny, W = ny, PL = nx * ny;  // P[k][i-1][j-1], interior only
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
   const int lane = threadIdx.x;
 #define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
   for (int t = lane; t < NZ * PL; t += NT) {
     const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W;
-    P[t] = G.p[GI(k0, j, i)];
+    P[t] = G.p[GI(k0, j + 1, i + 1)];
   }
   const int nbj = ny >> 1;
   const bool mine = lane < (nx >> 1) * nbj;
@@ -58,14 +62,16 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 #define COLUMN(q)                                                                                                          \
   {                                                                                                                         \
     const int i = 2 * bi + 1 + ((q) >> 1), j = 2 * bj + 1 + ((q) & 1);                                                       \
-    const bool mS = ph.S && j == 1, mN = ph.N && j == ny, mW = ph.W && i == 1, mE = ph.E && i == nx;                         \
+    /* the cell and its neighbours, clamped: at a side the neighbour is the image of the column itself */                    \
+    const int oc = (i - 1) * W + (j - 1);                                                                                   \
+    const int sjm = j > 1 ? -1 : 0, sjp = j < ny ? 1 : 0, sim = i > 1 ? -W : 0, sip = i < nx ? W : 0;                       \
     double x[NZ];                                                                                                           \
     double d1 = 0, d2 = 0, d3 = 0, d4 = 0;                                                                                  \
-    if (REAL) { d1 = Q1[(i - 1) * W + j + 1]; d2 = Q1[(i + 1) * W + j - 1]; d3 = Q1[(i - 1) * W + j - 1]; d4 = Q1[(i + 1) * W + j + 1]; } \
+    if (REAL) { d1 = Q1[oc + sim + sjp]; d2 = Q1[oc + sip + sjm]; d3 = Q1[oc + sim + sjm]; d4 = Q1[oc + sip + sjp]; }        \
     double pjm[NZ], pjp[NZ], pim[NZ], pip[NZ];                                                                              \
     _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
-      const int o = k * PL + i * W + j;                                                                                     \
-      pjm[k] = P[o - 1]; pjp[k] = P[o + 1]; pim[k] = P[o - W]; pip[k] = P[o + W];                                           \
+      const int o = k * PL + oc;                                                                                            \
+      pjm[k] = P[o + sjm]; pjp[k] = P[o + sjp]; pim[k] = P[o + sim]; pip[k] = P[o + sip];                                   \
     }                                                                                                                       \
     double xv = 0.0;                                                                                                        \
     _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
@@ -90,15 +96,7 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
     }                                                                                                                       \
     /* gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325): the same product as the stored pivot table, recomputed */              \
     _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - (a2[q][k + 1] * bet[q][k]) * x[k + 1];                \
-    _Pragma("unroll") for (int k = 0; k < NZ; k++) {                                                                        \
-      const int o = k * PL;                                                                                                 \
-      const double v = x[k];                                                                                                \
-      P[o + i * W + j] = v;                                                                                                 \
-      if (mS) P[o + i * W] = v;                                                                                             \
-      if (mN) P[o + i * W + ny + 1] = v;                                                                                    \
-      if (mW) { P[o + j] = v; if (mS) P[o] = v; if (mN) P[o + ny + 1] = v; }                                                \
-      if (mE) { P[o + (nx + 1) * W + j] = v; if (mS) P[o + (nx + 1) * W] = v; if (mN) P[o + (nx + 1) * W + ny + 1] = v; }   \
-    }                                                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < NZ; k++) P[k * PL + oc] = x[k];                                                   \
   }
   for (int it = 0; it < nsweeps; it++) {
     if (method == 2) {  // four colours (mg_relax.f90:212-230): (i odd,j odd), (i odd,j even), (i even,j odd), (i even,j even)
@@ -128,9 +126,12 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 #undef R6
 #undef R7
 #undef R8
-  for (int t = lane; t < NZ * PL; t += NT) {
-    const int k0 = t / PL, r = t - k0 * PL, ii = r / W, jj = r - ii * W;
-    G.p[GI(k0, jj, ii)] = P[t];
+  // write back, halo included: every halo cell is the image of the interior cell its indices clamp to
+  const int WH = ny + 2, PLH = (nx + 2) * WH;
+  for (int t = lane; t < NZ * PLH; t += NT) {
+    const int k0 = t / PLH, r = t - k0 * PLH, ii = r / WH, jj = r - ii * WH;
+    const int ci = ii < 1 ? 1 : (ii > nx ? nx : ii), cj = jj < 1 ? 1 : (jj > ny ? ny : jj);
+    G.p[GI(k0, jj, ii)] = P[k0 * PL + (ci - 1) * W + (cj - 1)];
   }
 #undef GI
 }
