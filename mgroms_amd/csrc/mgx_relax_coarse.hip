@@ -23,9 +23,16 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
   const int lane = threadIdx.x;
 #define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
-  for (int t = lane; t < NZ * PL; t += NT) {
-    const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W;
-    P[t] = G.p[GI(k0, j + 1, i + 1)];
+  {  // p -> LDS: at most 4 NZ cells per lane (<= 256 columns per wave), all loads in flight before the first LDS store
+    double tp[4 * NZ];
+#pragma unroll
+    for (int u = 0; u < 4 * NZ; u++) {
+      const int t = lane + u * NT;
+      tp[u] = 0.0;
+      if (t < NZ * PL) { const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W; tp[u] = G.p[GI(k0, j + 1, i + 1)]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * NZ; u++) { const int t = lane + u * NT; if (t < NZ * PL) P[t] = tp[u]; }
   }
   const int nbj = ny >> 1;
   const bool mine = lane < (nx >> 1) * nbj;
