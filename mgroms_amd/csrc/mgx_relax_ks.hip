@@ -13,10 +13,14 @@
 
 #include "mgx_device.h"
 
-template <int NZ, int NW, bool REAL, bool SNAP>
+// H > 1 (nz = 64, the second level of an nz = 128 hierarchy): a wave's NZ/NW rows are built in H runs of R rows one after the other (the register
+// arrays of a run are those of the nz = 32 kernel), the recurrence wave keeps only x(k) in registers and takes a2(k), bet(k) from LDS as it
+// goes, and the three parked arrays are dynamic LDS (96 KB).
+template <int NZ, int NW, bool REAL, bool SNAP, int H = 1>
 __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
-  constexpr int R = NZ / NW;  // rows per wave
-  __shared__ double sh[NZ * WAVE], sa2[NZ * WAVE], sbt[NZ * WAVE];  // rhs(k) then x(k); a2(k); bet(k): [k-1][lane]
+  constexpr int R = NZ / NW / H;  // rows per wave and run
+  extern __shared__ double ks_lds[];
+  double *__restrict__ sh = ks_lds, *__restrict__ sa2 = ks_lds + NZ * WAVE, *__restrict__ sbt = ks_lds + 2 * NZ * WAVE;  // rhs(k) then x(k); a2(k); bet(k): [k-1][lane]
   // XCD-aware block -> (j-chunk, plane) map, as k_relax_nz: each XCD owns a contiguous range of planes (speed only)
   int bx, ipl;
   if (gx < 0) { gx = -gx; ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }
@@ -41,13 +45,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
                *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
   const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
   const double qrt = 0.25;
-  const int ka = w * R + 1;  // first row of this wave
+  const int kw = w * R * H + 1;  // first row of this wave
 
   // ---- phase 1: right-hand sides of rows ka .. ka+R-1 (every load of the wave is issued before the first use)
   double pjm[R + 2], pim[R + 2], pjp[R + 2], pip[R + 2], zyo[R + 2], zxo[R + 2];  // rows ka-1 .. ka+R
   double bb[R], a4o[R], a7o[R], a4n[R], a7n[R], zyjm[R], zyjp[R], zxim[R], zxip[R];
   double oa2[R], obt[R];  // the recurrence's coefficients of the wave's rows: handed to wave 0 through LDS
   double d1 = 0, d2 = 0, d3 = 0, d4 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+#pragma unroll 1
+  for (int run = 0; run < H; run++) {
+  const int ka = kw + run * R;  // first row of this run
   if (live) {
 #pragma unroll
     for (int r = 0; r < R + 2; r++) {
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
       zyjm[r] = zy[o + ro + jm]; zyjp[r] = zy[o + ro + jp]; zxim[r] = zx[om + ro + c]; zxip[r] = zx[op + ro + c];
       oa2[r] = a2[o + ro + c]; obt[r] = bet[o + ro + c];
     }
-    if (w == 0) {
+    if (w == 0 && run == 0) {
       if (REAL) {
         const double *__restrict__ q1 = SNAP ? L.p1 : p;
         const long long s = SNAP ? (long long)i * RS : o, sm = SNAP ? s - RS : om, sp = SNAP ? s + RS : op;
@@ -101,8 +108,25 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
       sbt[(k - 1) * WAVE + lane] = obt[r];
     }
   }
+  }
   __syncthreads();
   // ---- phase 2 (wave 0): tridiag (mg_relax.f90:322-332) on the parked right-hand sides
+  if (H > 1) {
+    if (w == 0 && live) {  // x(k) in registers only; a2(k), bet(k) stream from LDS (their addresses do not depend on the recurrence)
+      double x[NZ];
+      double xv = sh[lane] * sbt[lane];
+      x[0] = xv;
+#pragma unroll
+      for (int k = 2; k <= NZ; k++) {
+        xv = (sh[(k - 1) * WAVE + lane] - sa2[(k - 1) * WAVE + lane] * xv) * sbt[(k - 1) * WAVE + lane];
+        x[k - 1] = xv;
+      }
+#pragma unroll
+      for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - (sa2[k * WAVE + lane] * sbt[(k - 1) * WAVE + lane]) * x[k];  // gam(k+1) = dd(k)*bet(k)
+#pragma unroll
+      for (int k = 1; k <= NZ; k++) sh[(k - 1) * WAVE + lane] = x[k - 1];
+    }
+  } else
   if (w == 0 && live) {
     double x[NZ], g[NZ], ra2[NZ], rbt[NZ];
 #pragma unroll
@@ -144,8 +168,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
   const int cS = L.EO, cN = jpos(L, L.ny + 1);
   const long long oW = 0, oE = (long long)(L.nx + 1) * L.plane;
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int k = ka + r;
+  for (int r = 0; r < R * H; r++) {
+    const int k = kw + r;
     const long long ro = (long long)(k - 1) * RS;
     const double v = sh[(k - 1) * WAVE + lane];
     p[o + ro + c] = v;
@@ -345,7 +369,8 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
   static const bool off = getenv("MGX_NO_KS") != nullptr, noxcd = getenv("MGX_NO_XCD") != nullptr;
   static const int nw_env = getenv("MGX_KS_NW") ? atoi(getenv("MGX_KS_NW")) : 0;
   static const bool ks8 = getenv("MGX_NO_KS8") == nullptr;
-  if (off || L->zy == nullptr || (L->nz != 32 && L->nz != 16 && !(L->nz == 8 && ks8))) return 0;
+  static const bool ks64 = getenv("MGX_NO_KS64") == nullptr;
+  if (off || L->zy == nullptr || (L->nz != 32 && L->nz != 16 && !(L->nz == 8 && ks8) && !(L->nz == 64 && ks64 && !snap))) return 0;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE;
   // worth it only while a colour has fewer waves than the chip has SIMDs (1024); a bandwidth-bound level keeps one wave per column set
   if (gx0 * nplanes > 512) return 0;
@@ -355,10 +380,24 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
 #define KS_LAUNCH(NZV, NWV)                                                                                                     \
   {                                                                                                                              \
     dim3 blk(WAVE, NWV);                                                                                                         \
-    if (real && snap) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
-    else if (real) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);     \
-    else hipLaunchKernelGGL((k_relax_ks<NZV, NWV, false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);              \
+    const size_t lds = (size_t)3 * NZV * WAVE * sizeof(double);                                                                  \
+    if (real && snap) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, true>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
+    else if (real) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);     \
+    else hipLaunchKernelGGL((k_relax_ks<NZV, NWV, false, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);              \
     return 1;                                                                                                                    \
+  }
+  if (L->nz == 64) {  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+    static bool attr = false;
+    const size_t lds = (size_t)3 * 64 * WAVE * sizeof(double);
+    if (!attr) {
+      if (hipFuncSetAttribute((const void *)k_relax_ks<64, 8, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void *)k_relax_ks<64, 8, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+      attr = true;
+    }
+    dim3 blk(WAVE, 8);
+    if (real) hipLaunchKernelGGL((k_relax_ks<64, 8, true, false, 2>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+    else hipLaunchKernelGGL((k_relax_ks<64, 8, false, false, 2>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
+    return 1;
   }
   // measured (256x256x32 / 128x128x16, four-colour sweep): 8 waves 47.0 / 21.6 us, 4 waves 53.3 / 23.3, row by row 57.6 / 28.2
   if (L->nz == 32) { if (nw_env == 4) KS_LAUNCH(32, 4) else KS_LAUNCH(32, 8) }
