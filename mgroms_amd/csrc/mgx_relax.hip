@@ -818,6 +818,9 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
     return 1;
   }
   if (ncol > 256 || L->nz > 8) return 0;
+  // 32x32x8 (fifth level of an nz = 128 hierarchy), four colours: two colour-pair launches per sweep (k_relax_ks2, 5.9 us each) beat this
+  // kernel's 22-32 us per sweep, which re-reads every operand through L2
+  if (L->nz == 8 && method == 2 && L->zy != nullptr && ncol > 64 && L->ny / 2 <= WAVE) return 0;
   const int nth = ncol <= 64 ? 64 : 256;
 #define SMALL_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_small<NZV, true, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph, exact); \
                                   else hipLaunchKernelGGL((k_relax_small<NZV, false, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph, exact); return 1;
