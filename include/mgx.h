@@ -165,6 +165,10 @@ int mgx_print_tictoc(const char *path);
 /* ---- measurement helpers used by bench.py (timed with HIP events on the solver's stream) ---- */
 /* run `reps` smoother sweeps on level `lev` (reps x relax(lev,1)); *ms = average milliseconds per sweep */
 int mgx_time_relax(int lev, int reps, float *ms);
+/* self-test of the arithmetic identity the level-1 colour pass relies on for its per-column divisors: a[i] / b[i] by
+ * the hardware fp64 division sequence against the refined-reciprocal quotient; *nbad = pairs whose bits differ (0 for operands whose
+ * quotient and operands sit in the normal range).  Host arrays; needs no mgx_init. */
+int mgx_selftest_divc(const double *a, const double *b, int n, long long *nbad);
 int mgx_time_residual(int lev, int reps, float *ms);
 /* counters since mgx_init: out[0]=kernel launches, out[1]=halo fills, out[2]=exchanges, out[3]=allreduces */
 int mgx_counters(long long *out);

@@ -57,6 +57,7 @@ _SIGS = {
     "mgx_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "mgx_print_tictoc": (C.c_int, [C.c_char_p]),
     "mgx_time_relax": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "mgx_selftest_divc": (C.c_int, [_DP, _DP, C.c_int, C.POINTER(C.c_longlong)]),
     "mgx_time_residual": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_counters": (C.c_int, [C.POINTER(C.c_longlong)]),
     "mgx_p2p_handle_bytes": (C.c_int, []),

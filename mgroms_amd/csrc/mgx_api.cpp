@@ -39,6 +39,7 @@ void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, doub
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int, int);
+void mgxk_divc_selftest(hipStream_t, const double *, const double *, int, unsigned long long *);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, double *const *, unsigned long long *const *,
@@ -1408,6 +1409,21 @@ static int time_op(int lev, int reps, float *ms, int which) {
   float t = 0; HIPCHK(hipEventElapsedTime(&t, e0, e1));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *ms = t / reps;
+  return 0;
+}
+// a[i] / b[i] by the hardware division sequence against the refined-reciprocal quotient the colour pass uses for its per-column
+// divisors (DIVC, mgx_device.h): *nbad = number of pairs whose bits differ.  Needs no mgx_init.
+int mgx_selftest_divc(const double *a, const double *b, int n, long long *nbad) {
+  if (n < 1) return fail("mgx_selftest_divc: n must be >= 1");
+  double *da = nullptr, *db = nullptr; unsigned long long *dbad = nullptr, h = 0;
+  HIPCHK(hipMalloc((void **)&da, (size_t)n * sizeof(double))); HIPCHK(hipMalloc((void **)&db, (size_t)n * sizeof(double))); HIPCHK(hipMalloc((void **)&dbad, sizeof h));
+  HIPCHK(hipMemcpy(da, a, (size_t)n * sizeof(double), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dbad, 0, sizeof h));
+  mgxk_divc_selftest(nullptr, da, db, n, dbad);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&h, dbad, sizeof h, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dbad);
+  *nbad = (long long)h;
   return 0;
 }
 int mgx_time_relax(int lev, int reps, float *ms) { return time_op(lev, reps, ms, 0); }

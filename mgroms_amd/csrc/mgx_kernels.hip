@@ -720,6 +720,14 @@ __global__ void k_split(LevView C, LevView Cs, const double *__restrict__ pc, do
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
+// self-test of the constant-divisor quotient (mgx_device.h, DIVC): a / b by the hardware sequence against the refined-reciprocal form
+__global__ void k_divc_selftest(const double *__restrict__ a, const double *__restrict__ b, int n, unsigned long long *bad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double q = a[t] / b[t], rb = RCP_REF(b[t]), c = DIVC(a[t], b[t], rb);
+  if (__double_as_longlong(q) != __double_as_longlong(c)) atomicAdd(bad, 1ull);
+}
+
 extern "C" {
 
 int mgxk_residual_nblocks(const LevView *L) { dim3 g = col_grid(L->ny / 2, L->nx, 2); return g.x * g.y * g.z; }
@@ -772,6 +780,9 @@ void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const 
   if (linear) { if (keep_r) C2F(true, true); else C2F(true, false); }
   else { if (keep_r) C2F(false, true); else C2F(false, false); }
 #undef C2F
+}
+void mgxk_divc_selftest(hipStream_t st, const double *a, const double *b, int n, unsigned long long *bad) {
+  hipLaunchKernelGGL(k_divc_selftest, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, bad);
 }
 void mgxk_halo_phys(hipStream_t st, const LevView *L, double *a, Sides ph) {
   const int n = L->nx + L->ny + 1;

@@ -538,6 +538,25 @@ def test_cycle_keeps_the_dead_r_on_request(mg):
         assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
 
 
+def test_constant_divisor_quotient_is_the_hardware_quotient(mg):
+    # The colour pass divides by per-column constants through a reciprocal refined with the two Newton steps of the hardware fp64
+    # division sequence and then that sequence's last three operations (DIVC, mgx_device.h).  Same operations on the same values as
+    # `/` while nothing needs rescaling: bit-identical for every pair below (magnitudes far beyond any depth or metric factor, zero and
+    # negative numerators included).
+    import ctypes as C
+    from mgroms_amd._lib import lib, check
+    r = np.random.default_rng(7)
+    n = 1 << 20
+    a = r.standard_normal(n) * 10.0 ** r.uniform(-100, 100, n)
+    b = (r.uniform(0.5, 2.0, n) * 10.0 ** r.uniform(-100, 100, n)) * np.where(r.random(n) < 0.5, 1.0, -1.0)
+    a[:1000] = 0.0
+    a[1000:2000] = b[1000:2000]          # quotient exactly one
+    b[2000:3000] = 2.0 ** r.integers(-50, 50, 1000)   # powers of two
+    nbad = C.c_longlong(-1)
+    check(lib().mgx_selftest_divc(a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(nbad)))
+    assert nbad.value == 0
+
+
 def test_fortran_harness(mg, tmp_path):
     """The reference's driver shape in Fortran (fortran/mg_testseamount_gpu.f90) over module nhydro -> ISO_C_BINDING
     -> libmgx.so: same residual history as the oracle, printed in the reference's format."""
