@@ -968,28 +968,50 @@ int mgx_params_default(mgx_params *p) {
 int mgx_read_namelist(const char *path, mgx_params *p) {
   FILE *f = fopen(path ? path : "nh_namelist", "r");
   if (!f) return 0;  // defaults stay (mg_namelist.f90:75-86)
+  // Fortran namelist rules as far as /nhparam/ needs them (checked against read_nhnamelist of the reference compiled with flang,
+  // tests/golden/ref_namelist.json): group and member names in any case; `!` starts a comment outside a string; assignments are
+  // separated by commas, blanks or line ends; the group ends at `/`.
   std::string txt; char line[1024];
-  while (fgets(line, sizeof(line), f)) { std::string s(line); size_t c = s.find('!'); if (c != std::string::npos) s = s.substr(0, c); txt += s + "\n"; }
+  while (fgets(line, sizeof(line), f)) {
+    std::string s(line); char q = 0; size_t c = std::string::npos;
+    for (size_t t = 0; t < s.size(); t++) {
+      if (q) { if (s[t] == q) q = 0; }
+      else if (s[t] == '\'' || s[t] == '"') q = s[t];
+      else if (s[t] == '!') { c = t; break; }
+    }
+    if (c != std::string::npos) s = s.substr(0, c);
+    txt += s + "\n";
+  }
   fclose(f);
-  size_t a = txt.find("&nhparam");
+  std::string low = txt;
+  for (auto &ch : low) ch = (char)tolower(ch);
+  size_t a = low.find("&nhparam");
   if (a == std::string::npos) return fail("namelist group &nhparam not found in %s", path ? path : "nh_namelist");
-  size_t e = txt.find('/', a);
-  std::string body = txt.substr(a + 8, e == std::string::npos ? std::string::npos : e - a - 8);
-  size_t pos = 0;
-  while (pos < body.size()) {  // scalar assignments "key = value", separated by commas and/or newlines
-    size_t end = body.find_first_of(",\n", pos);
-    if (end == std::string::npos) end = body.size();
-    std::string stmt = body.substr(pos, end - pos);
-    pos = end + 1;
-    size_t eq = stmt.find('=');
-    if (eq == std::string::npos) { trim(stmt); if (!stmt.empty()) return fail("cannot parse namelist statement '%s'", stmt.c_str()); continue; }
-    std::string key = stmt.substr(0, eq), val = stmt.substr(eq + 1);
-    trim(key); trim(val);
-    for (auto &ch : key) ch = (char)tolower(ch);
-    std::string sv = val;
-    if (sv.size() >= 2 && (sv[0] == '\'' || sv[0] == '"')) sv = sv.substr(1, sv.size() - 2);
+  size_t pos = a + 8;
+  const std::string ws = " \t\r\n,";
+  for (;;) {
+    pos = txt.find_first_not_of(ws, pos);
+    if (pos == std::string::npos || txt[pos] == '/') break;
+    size_t ke = pos;
+    while (ke < txt.size() && (isalnum((unsigned char)txt[ke]) || txt[ke] == '_')) ke++;
+    size_t eq = txt.find_first_not_of(" \t\r\n", ke);
+    if (ke == pos || eq == std::string::npos || txt[eq] != '=') return fail("cannot parse namelist statement near '%s'", txt.substr(pos, 24).c_str());
+    std::string key = low.substr(pos, ke - pos);
+    size_t vb = txt.find_first_not_of(" \t\r\n", eq + 1), ve;
+    if (vb == std::string::npos) return fail("namelist member '%s' has no value", key.c_str());
+    std::string val, sv;
+    if (txt[vb] == '\'' || txt[vb] == '"') {
+      ve = txt.find(txt[vb], vb + 1);
+      if (ve == std::string::npos) return fail("unterminated string for namelist member '%s'", key.c_str());
+      sv = txt.substr(vb + 1, ve - vb - 1); val = sv; ve++;
+    } else {
+      ve = txt.find_first_of(" \t\r\n,/", vb);
+      if (ve == std::string::npos) ve = txt.size();
+      val = txt.substr(vb, ve - vb); sv = val;
+    }
+    pos = ve;
     auto num = [&](void) { std::string t = val; for (auto &ch : t) if (ch == 'd' || ch == 'D') ch = 'e'; return atof(t.c_str()); };
-    auto lg = [&](void) { std::string t = val; for (auto &ch : t) ch = (char)tolower(ch); return (t.find(".t") == 0 || t == "t") ? 1 : 0; };
+    auto lg = [&](void) { std::string t = val; for (auto &ch : t) ch = (char)tolower(ch); return (t.find(".t") == 0 || t.find("t") == 0) ? 1 : 0; };
     if (key == "solver_prec") p->solver_prec = num();
     else if (key == "solver_maxiter") p->solver_maxiter = (int)num();
     else if (key == "nsmall") p->nsmall = (int)num();
@@ -1312,17 +1334,19 @@ int mgx_print_tictoc(const char *path) {
   tt_collect();
   FILE *f = fopen(path ? path : "fort.10", "w");
   if (!f) return fail("cannot open %s", path ? path : "fort.10");
+  // the reference's formats (mg_tictoc.f90:128-150): t22 + A10, (x,I9) per level; per timer (x,A20), (x,E9.3) total and per level, then
+  // the call counts under them -- byte for byte what flang writes (tests/golden/ref_tictoc.txt), E9.3 in Fortran's 0.dddE+ee form
   fprintf(f, "%21s%10s", "", "Total");
   for (int l = 1; l <= tt_nblev; l++) fprintf(f, " %9d", l);
-  fprintf(f, " \n");
+  fprintf(f, "\n");
   for (size_t q = 0; q < tt_names.size(); q++) {
     double tot = 0; long long nc = 0;
     for (int l = 0; l < tt_nblev; l++) { tot += tt_time[l][q]; nc += tt_calls[l][q]; }
-    fprintf(f, " %20s %9.3E", tt_names[q].c_str(), tot);
-    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %9.3E", tt_time[l][q]);
-    fprintf(f, " \n%21s %9lld", "", nc);
+    fprintf(f, " %20s %s", tt_names[q].c_str(), fortran_e3(tot, 9).c_str());
+    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %s", fortran_e3(tt_time[l][q], 9).c_str());
+    fprintf(f, "\n%21s %9lld", "", nc);
     for (int l = 0; l < tt_nblev; l++) fprintf(f, " %9lld", tt_calls[l][q]);
-    fprintf(f, " \n");
+    fprintf(f, "\n");
   }
   fclose(f);
   return 0;

@@ -15,11 +15,13 @@
  * the reference's decomposition-dependent behaviour (e.g. the order dependence
  * of the red-black sweep at k=1) reproducible without MPI.
  *
- * Parity status: PARITY UNPINNED under this build's rule.  The reference holds no golden vectors, known-answer tests or
- * fixtures for this path, and it cannot be built here (it needs netcdf-fortran, which the image lacks, and an `mpi` module
- * readable by flang: both would have to be hand-written stand-ins, which the rules exclude), so no oracle/_ref exists.
- * What this file is checked against (tests/test_oracle.py) are the known answers of BASELINE.md section 3, committed as
- * tests/golden/baseline_known_answers.json: outputs of the reference recorded by the survey from such a stand-in build
+ * Parity status: PARITY UNPINNED for the solver path; PINNED for setup_zr_zw.  The reference holds no golden vectors,
+ * known-answer tests or fixtures for this path.  Three of its modules compile here unmodified (mg_zr_zw, mg_namelist, mg_tictoc:
+ * `make -C oracle ref` -> oracle/_ref, driver oracle/ref_driver.f90): this file's setup_zr_zw is bit-identical to the
+ * reference-compiled one on six cases incl. the cosh / exp branches (tests/golden/ref_zrzw.npz, tests/test_oracle.py).  The
+ * solver modules cannot be built (netcdf-fortran is absent and the image's `mpi.mod` is unreadable by flang: both would have to be
+ * hand-written stand-ins, which the rules exclude).  For them this file is checked against the known answers of BASELINE.md
+ * section 3 (tests/golden/baseline_known_answers.json): outputs of the reference recorded by the survey from such a stand-in build
  * (flang -O2 + MPICH), with no recipe committed -- strong circumstantial evidence (15 RB residuals to 1e-13 including the
  * reference's decomposition-dependent 2x2 series, FC on 1 and 2x2 ranks, sums and samples of p, a dense direct solve), not a pin.
  *

@@ -454,6 +454,53 @@ def test_warm_start_and_tictoc(mg, tmp_path):
     assert "Total" in txt and "relax_3D_8_FC" in txt and "residual_3D_8" in txt and "Fcycle" in txt and "solve" in txt
     rows = [l for l in txt.splitlines() if "relax_3D_8_FC" in l]
     assert float(rows[0].split()[1]) > 0
+    # byte format of print_tictoc (mg_tictoc.f90:114-153) against what the reference module itself writes (compiled unmodified with
+    # flang: tests/golden/ref_tictoc.txt, oracle/make_ref_golden.py): same line shapes once digits are masked and names removed
+    import os
+    import re
+    ref = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tictoc.txt")).read().splitlines()
+    shape = lambda l: re.sub(r"[0-9]", "#", re.sub(r"E[+-]", "E~", l))
+    mine = txt.splitlines()
+    nl = mg.nlevs()
+    assert mine[0] == "%21s%10s" % ("", "Total") + "".join(" %9d" % l for l in range(1, nl + 1))
+    assert shape(ref[0])[:41] == shape(mine[0])[:41]
+    tl, cl = shape(ref[1]), shape(ref[2])   # a timer line and its call-count line, three levels wide in the fixture
+    for k in range(1, len(mine), 2):
+        assert shape(mine[k])[22:22 + 10] == tl[22:32] and len(mine[k]) == 21 + 10 * (nl + 1), mine[k]        # " 0.###E~##" columns
+        assert re.fullmatch(r" {21}( +#+){%d}" % (nl + 1), shape(mine[k + 1])) and len(mine[k + 1]) == len(mine[k]), mine[k + 1]
+        assert all(shape(mine[k])[c:c + 10] == tl[22:32] for c in range(21, len(mine[k]), 10))
+    assert cl.startswith(" " * 21)
+
+
+def test_zr_zw_kernel_against_reference_compiled_module(mg):
+    """Row a13 on the device against the REAL reference: tests/golden/ref_zrzw.npz = zr, zw written by setup_zr_zw of
+    mg_zr_zw.f90 compiled unmodified with flang (oracle/Makefile target `ref`).  theta = 0: no transcendental function, k_zr_zw
+    must give the same bits.  theta_s, theta_b > 0: the sigma tables call cosh / exp -- the device's libm against glibc -- so
+    the bound is stated in ulps of the depth scale: |d| <= 32 ulp(max|z|) (measured: a few ulp).  The level-1 colour pass rebuilds
+    zw / zr in registers from the same tables; that it equals these stored arrays bit for bit is
+    test_in_kernel_coefficients_match_stored_slots_on_stretched_grids (device against device)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_zrzw.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    assert len(names) >= 6
+    worst = 0.0
+    for n in names:
+        nx, ny, nz = (int(v) for v in z[n + "/par"][:3])
+        hlim, tb, ts = (float(v) for v in z[n + "/par"][3:])
+        mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(relax_method="FC"))
+        dx = np.full((nx + 2, ny + 2), 100.0)
+        mg.nhydro_matrices(dx, dx.copy(), z[n + "/zeta"].copy(), z[n + "/h"].copy(), None, hlim, tb, ts)
+        ring = (slice(1, -1), slice(1, -1))
+        for name in ("zr", "zw"):
+            a, g = mg.grid(1).get(name)[ring], z[n + "/" + name][ring]
+            if tb == 0.0 and ts == 0.0:
+                assert np.array_equal(a, g), (n, name)
+            else:
+                ulp = np.spacing(np.abs(g).max())
+                d = np.abs(a - g).max() / ulp
+                worst = max(worst, d)
+                assert d <= 32, (n, name, d)
+    print(f"zr/zw with cosh/exp tables: max deviation {worst:.1f} ulp of the depth scale")
 
 
 def test_error_behaviour(mg):

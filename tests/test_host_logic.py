@@ -83,6 +83,35 @@ def test_namelist_parser(built, tmp_path):
         nhydro.read_nhnamelist(str(h))
 
 
+def test_namelist_parser_against_reference_compiled_read(built, tmp_path):
+    """mgx_read_namelist against read_nhnamelist of the reference itself (mg_namelist.f90 compiled unmodified with flang,
+    oracle/Makefile target `ref`; fixtures tests/golden/ref_namelist.json made by oracle/make_ref_golden.py): defaults, every
+    member set, Fortran `d` exponents, .true. / T, mixed case, comments, a one-line group, and the linear+linear rejection of
+    :95-98 (which the reference shows at -O0 only: the branch reads `rank` uninitialised and flang -O2 deletes it)."""
+    import json
+    from mgroms_amd import nhydro
+    from mgroms_amd._lib import MgxError
+    with open(os.path.join(ROOT, "tests", "golden", "ref_namelist.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 8
+    for name, c in cases.items():
+        fn = tmp_path / name
+        fn.write_text(c["text"])
+        if not c["accepted"]:
+            with pytest.raises(MgxError):
+                nhydro.read_nhnamelist(str(fn))
+            continue
+        p = nhydro.read_nhnamelist(str(fn))
+        m = c["members"]
+        assert p.solver_prec == float(m["solver_prec"].replace("E-0", "E-").replace("E+0", "E+")), name
+        for k in ("solver_maxiter", "nsmall", "ns_coarsest", "ns_pre", "ns_post"):
+            assert getattr(p, k) == int(m[k]), (name, k)
+        for k in ("cmatrix", "relax_method", "interp_type", "restrict_type"):
+            assert getattr(p, k).decode() == m[k], (name, k)
+        for k in ("aggressive", "netcdf_output", "bmask"):
+            assert getattr(p, k) == (1 if m[k] == "T" else 0), (name, k)
+
+
 def test_no_cpu_fallback(built):
     import torch
     if torch.cuda.is_available():

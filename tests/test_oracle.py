@@ -273,3 +273,36 @@ def test_call_mask_semantics():
     assert not np.array_equal(b2, b3)            # the cross terms saw the land
     b4, _, _ = run(False, np.ones_like(mask))
     assert np.array_equal(b2, b4)                # an all-ones mask is the no-mask case
+
+
+# ---- genuine reference pin: mg_zr_zw.f90 compiled unmodified (oracle/_ref, `make -C oracle ref`) --------------------------
+def _zrzw_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_zrzw.npz"))
+    return z, sorted({k.split("/")[0] for k in z.files})
+
+
+def test_zr_zw_equal_the_reference_compiled_module():
+    """Row a13 against the REAL reference: tests/golden/ref_zrzw.npz holds zr, zw written by setup_zr_zw
+    (mg_zr_zw.f90:46-215, branch new_s_coord) of the reference compiled unmodified with flang (oracle/Makefile target `ref`,
+    driver oracle/ref_driver.f90, generator oracle/make_ref_golden.py) for theta = 0, for theta_s or theta_b alone, and for the
+    stretched coordinate (theta_s = 6, theta_b = 0.4, hc = 250) with zeta /= 0 at nz = 4 ... 128.  The oracle's restatement must
+    give the same bits on the whole 0:n+1 ring: with theta = 0 there is no libm call at all; with cosh / exp both sides call
+    the same glibc functions on the same arguments (the tables depend on k only).  The outer ring (-1, n+2) is filled later by
+    fill_halo(nh=2), not by setup_zr_zw, and is not compared."""
+    z, names = _zrzw_cases()
+    assert len(names) >= 6
+    for n in names:
+        nx, ny, nz = (int(v) for v in z[n + "/par"][:3])
+        hlim, tb, ts = (float(v) for v in z[n + "/par"][3:])
+        o = Oracle(nx, ny, nz, 1, 1, relax_method="FC")
+        o.field("h")[...] = z[n + "/h"]
+        o.field("zeta")[...] = z[n + "/zeta"]
+        o.field("dx")[...] = 100.0
+        o.field("dy")[...] = 100.0
+        o.matrices(hlim, tb, ts)
+        ring = (slice(1, -1), slice(1, -1))
+        assert np.array_equal(o.field("zr")[ring], z[n + "/zr"][ring]), n
+        assert np.array_equal(o.field("zw")[ring], z[n + "/zw"][ring]), n
+        assert np.all(z[n + "/zw"][ring][..., -1] == z[n + "/zeta"]), n  # the free surface is the last interface
+        o.close()
