@@ -7,7 +7,8 @@
  * `nhydro` with the reference's five signatures forwards to these through
  * ISO_C_BINDING (fortran/nhydro.f90).  Like the reference
  * (module-global `grid(:)`, mg_grids.f90:113-117) the library holds ONE solver
- * instance per process; one process drives one GPU.
+ * instance per process unless the caller asks for more (mgx_instance_*, below);
+ * one process drives one GPU.
  *
  * Conventions
  *  - all arrays are host pointers to double (real(kind=8)); the library owns
@@ -186,6 +187,21 @@ int mgx_p2p_handle_bytes(void);
 int mgx_p2p_prepare(void *handles_out);
 int mgx_p2p_connect(const void *all_handles, int nranks);
 long long mgx_p2p_exchanges(void);
+
+/* ---- more than one solver in a process (the reference has exactly one: module-global grid(:), mg_grids.f90:113-117) ----
+ * Instance 0 exists from the start and is what every thread acts on.  mgx_instance_create returns the id of a new, empty
+ * instance; mgx_instance_select(id) makes all later mgx_* calls OF THE CALLING THREAD act on it (thread-local selection:
+ * one thread per instance may run concurrently; two threads must not drive the same instance at the same time).  Uses:
+ * several nested domains coupled from one process; several ranks of one job as threads of one process (each with its own
+ * stream, mgx_set_stream) where a box admits fewer processes than ranks -- they are connected with mgx_set_comm hooks or with
+ * mgx_p2p_prepare + mgx_p2p_local_pointers + mgx_p2p_connect_pointers (same-process buffers need no hipIpc).
+ * mgx_instance_destroy frees an instance (never 0); mgx_instance_current returns the calling thread's id. */
+int mgx_instance_create(void);
+int mgx_instance_select(int id);
+int mgx_instance_current(void);
+int mgx_instance_destroy(int id);
+int mgx_p2p_local_pointers(void **slab, void **flags);
+int mgx_p2p_connect_pointers(void *const *slabs, void *const *flags, int nranks);
 
 const char *mgx_last_error(void);
 const char *mgx_version(void);

@@ -64,6 +64,12 @@ _SIGS = {
     "mgx_p2p_prepare": (C.c_int, [C.c_void_p]),
     "mgx_p2p_connect": (C.c_int, [C.c_void_p, C.c_int]),
     "mgx_p2p_exchanges": (C.c_longlong, []),
+    "mgx_p2p_local_pointers": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mgx_p2p_connect_pointers": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
+    "mgx_instance_create": (C.c_int, []),
+    "mgx_instance_select": (C.c_int, [C.c_int]),
+    "mgx_instance_current": (C.c_int, []),
+    "mgx_instance_destroy": (C.c_int, [C.c_int]),
     "mgx_rccl_unique_id_bytes": (C.c_int, []),
     "mgx_rccl_get_unique_id": (C.c_int, [C.c_void_p]),
     "mgx_rccl_connect": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -87,6 +88,8 @@ int mgxr_allgather(hipStream_t, const int *, int, const double *, double *, int)
 namespace {
 
 enum { M_GS = 0, M_RB = 1, M_FC = 2 };
+inline bool all_physical(const Sides &s) { return s.S && s.E && s.N && s.W; }
+inline bool any_physical(const Sides &s) { return s.S || s.E || s.N || s.W; }
 
 struct Level {
   int nx, ny, nz, npx, npy, incx, incy, gather, ngx, ngy, key, color;
@@ -109,6 +112,8 @@ struct Level {
   double *zg_store[4] = {nullptr, nullptr, nullptr, nullptr};  // dx2,dy2,cffr,csr (LevView)
 };
 
+struct TicRec { int lev, sub; hipEvent_t e0, e1; };
+
 struct State {
   bool inited = false, have_matrix = false;
   mgx_params par;
@@ -125,7 +130,7 @@ struct State {
   double *xbuf[16]; size_t xbuf_n = 0;                       // 8 send + 8 receive halo buffers
   // peer-to-peer halo transport (mgx_p2p_prepare / mgx_p2p_connect): receive slab + flags in fine-grained device memory,
   // the same slab and flags of every other rank opened through hipIpc
-  bool p2p_ready = false, p2p_on = false;
+  bool p2p_ready = false, p2p_on = false, p2p_borrowed = false;  // borrowed: peers are plain pointers (mgx_p2p_connect_pointers)
   double *p2p_slab = nullptr; size_t p2p_slab_n = 0;
   unsigned long long *p2p_flags = nullptr;
   std::vector<double *> peer_slab; std::vector<unsigned long long *> peer_flags;
@@ -147,10 +152,25 @@ struct State {
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
-  std::string err;
+  std::string err, transport_name;
+  // mg_tictoc.f90's module variables (subname, time, calls, nblev) + the HIP events still in flight
+  std::vector<std::string> tt_names;
+  std::vector<TicRec> tt_open, tt_done;
+  double tt_time[32][32] = {};
+  long long tt_calls[32][32] = {};
+  int tt_nblev = 0;
 };
 
-State S;
+// Instances.  The reference keeps ONE solver per process in module-global state (grid(:), mg_grids.f90:113-117), and so does every
+// caller that never asks for more: instance 0 exists from the start and every thread acts on it.  A thread may select another
+// instance (mgx_instance_create / mgx_instance_select): all mgx_* calls of THAT thread then act on it.  Used to couple several
+// domains from one process and to run several ranks of one job as threads of one process (tests: BASELINE config 5's 4x2 grid on
+// the one GPU of a test box, which admits fewer processes than that).
+State S0;
+std::vector<State *> g_instances = {&S0};
+std::mutex g_instances_mu;
+thread_local State *Sp = &S0;
+#define S (*Sp)
 int sync_stream();
 void p2p_release();
 
@@ -253,7 +273,7 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false, bool xonly = false
   S.n_halo++;
   const int *nb = L.neighb;
   Sides ph = {nb[0] < 0, nb[1] < 0, nb[2] < 0, nb[3] < 0};
-  if (!phys_done && (ph.S || ph.E || ph.N || ph.W)) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
+  if (!phys_done && any_physical(ph)) { mgxk_halo_phys(S.stream, &L.v, a, ph); S.n_launch++; }
   int n = 0, peer[8], cnt[8], present[8];
   double *sb[8], *rb[8];
   for (int d = 0; d < 8; d++) {
@@ -381,17 +401,11 @@ int global_sum(const Level &L, double *out) {
 
 
 // ---- mg_tictoc.f90: tic(lev,name) / toc(lev,name) / print_tictoc, timed with HIP events on the solver's stream ----
-struct TicRec { int lev, sub; hipEvent_t e0, e1; };
-std::vector<std::string> tt_names;
-std::vector<TicRec> tt_open, tt_done;
-double tt_time[32][32];
-long long tt_calls[32][32];
-int tt_nblev = 0;
 
 int tt_sub(const char *name) {
-  for (size_t q = 0; q < tt_names.size(); q++) if (tt_names[q] == name) return (int)q;
-  tt_names.push_back(name);
-  return (int)tt_names.size() - 1;
+  for (size_t q = 0; q < S.tt_names.size(); q++) if (S.tt_names[q] == name) return (int)q;
+  S.tt_names.push_back(name);
+  return (int)S.tt_names.size() - 1;
 }
 void tic(int lev, const char *name) {
   if (!S.tictoc) return;
@@ -399,29 +413,29 @@ void tic(int lev, const char *name) {
   if (r.sub >= 32 || lev > 32) return;
   (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, S.stream);
-  tt_open.push_back(r);
+  S.tt_open.push_back(r);
 }
 void toc(int lev, const char *name) {
   if (!S.tictoc) return;
   const int sub = tt_sub(name);
-  for (int q = (int)tt_open.size() - 1; q >= 0; q--)
-    if (tt_open[q].lev == lev && tt_open[q].sub == sub) {
-      (void)hipEventRecord(tt_open[q].e1, S.stream);
-      tt_done.push_back(tt_open[q]);
-      tt_open.erase(tt_open.begin() + q);
-      if (lev > tt_nblev) tt_nblev = lev;
+  for (int q = (int)S.tt_open.size() - 1; q >= 0; q--)
+    if (S.tt_open[q].lev == lev && S.tt_open[q].sub == sub) {
+      (void)hipEventRecord(S.tt_open[q].e1, S.stream);
+      S.tt_done.push_back(S.tt_open[q]);
+      S.tt_open.erase(S.tt_open.begin() + q);
+      if (lev > S.tt_nblev) S.tt_nblev = lev;
       return;
     }
 }
 void tt_collect() {
-  if (tt_done.empty()) return;
+  if (S.tt_done.empty()) return;
   (void)hipStreamSynchronize(S.stream);
-  for (auto &r : tt_done) {
+  for (auto &r : S.tt_done) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { tt_time[r.lev - 1][r.sub] += ms * 1e-3; tt_calls[r.lev - 1][r.sub]++; }
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { S.tt_time[r.lev - 1][r.sub] += ms * 1e-3; S.tt_calls[r.lev - 1][r.sub]++; }
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
-  tt_done.clear();
+  S.tt_done.clear();
 }
 struct TicScope { int lev; const char *name; TicScope(int l, const char *n) : lev(l), name(n) { tic(l, n); } ~TicScope() { toc(lev, name); } };
 
@@ -430,7 +444,7 @@ struct TicScope { int lev; const char *name; TicScope(int l, const char *n) : le
 int relax(int lev, int nsweeps) {
   Level &L = S.lev[lev - 1];
   TicScope ts(lev, S.method == M_RB ? "relax_3D_8_RB" : (S.method == M_FC ? "relax_3D_8_FC" : "relax_3D_8_GS"));  // mg_relax.f90:128,167,209
-  if (S.tictoc && tt_done.size() > 4096) tt_collect();
+  if (S.tictoc && S.tt_done.size() > 4096) tt_collect();
   if (S.method == M_GS) {  // exact lexicographic order by hyperplanes; halo fill once per sweep (mg_relax.f90:131-141)
     for (int it = 1; it <= nsweeps; it++) {
       if (!mgxk_relax_gs_sweep(S.stream, &L.v, S.real)) return fail("relax_method='GS': nz=%d has no register-resident kernel (nz must be a power of two <= 64)", L.nz);
@@ -442,7 +456,7 @@ int relax(int lev, int nsweeps) {
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   const int exact = S.method == M_RB && S.real && S.rb_exact;
   if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact)) { S.n_launch++; return 0; }
-  const bool closed = ph.S && ph.E && ph.N && ph.W;
+  const bool closed = all_physical(ph);
   double *const p1a = L.v.p1;
   for (int it = 1; it <= nsweeps; it++) {
     if (exact) {
@@ -519,7 +533,7 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
   };
   if (!C.gather) {
     // closed level: the kernel also zeroes p_c and, for Fcycle, duplicates b_c into r_c (whole arrays through the mirrors)
-    fused = phc.S && phc.E && phc.N && phc.W;
+    fused = all_physical(phc);
     const int d = down(&C.v, C.v.b, phc, fused ? C.v.p : nullptr);
     if (d < 0) return 1;
     if (!d) { mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc, fused && dup_r ? C.v.r : nullptr, fused ? C.v.p : nullptr); S.n_launch++; }
@@ -841,7 +855,7 @@ bool streq(const char *a, const char *b) { return strcmp(a, b) == 0; }
 // ---- peer-to-peer halo transport: set-up / tear-down ---------------------------------------------------------
 void p2p_release() {
   for (int r = 0; r < (int)S.peer_slab.size(); r++) {
-    if (r == S.rank) continue;
+    if (r == S.rank || S.p2p_borrowed) continue;
     if (S.peer_slab[r]) (void)hipIpcCloseMemHandle(S.peer_slab[r]);
     if (S.peer_flags[r]) (void)hipIpcCloseMemHandle(S.peer_flags[r]);
   }
@@ -851,7 +865,7 @@ void p2p_release() {
   if (S.p2p_counter) (void)hipFree(S.p2p_counter);
   if (S.p2p_err) (void)hipHostFree(S.p2p_err);
   S.p2p_slab = nullptr; S.p2p_flags = nullptr; S.p2p_counter = nullptr; S.p2p_err = nullptr;
-  S.p2p_ready = S.p2p_on = false;
+  S.p2p_ready = S.p2p_on = S.p2p_borrowed = false;
 }
 
 // stream synchronise + the peer-to-peer error word (a neighbour that never raised its flag)
@@ -891,6 +905,41 @@ void trim(std::string &s) {
 
 // ====================================================================================================
 extern "C" {
+
+// ---- instances (see the comment at State S0) --------------------------------------------------------------------------------
+int mgx_instance_create(void) {
+  std::lock_guard<std::mutex> lk(g_instances_mu);
+  for (size_t q = 1; q < g_instances.size(); q++) if (!g_instances[q]) { g_instances[q] = new State(); return (int)q; }
+  g_instances.push_back(new State());
+  return (int)g_instances.size() - 1;
+}
+int mgx_instance_select(int id) {
+  std::lock_guard<std::mutex> lk(g_instances_mu);
+  if (id < 0 || id >= (int)g_instances.size() || !g_instances[id]) return fail("mgx_instance_select: no instance %d", id);
+  Sp = g_instances[id];
+  return 0;
+}
+int mgx_instance_current(void) {
+  std::lock_guard<std::mutex> lk(g_instances_mu);
+  for (size_t q = 0; q < g_instances.size(); q++) if (g_instances[q] == Sp) return (int)q;
+  return -1;
+}
+// the calling thread must have selected another instance (or 0) before; instance 0 cannot be destroyed
+int mgx_instance_destroy(int id) {
+  State *victim = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_instances_mu);
+    if (id < 1 || id >= (int)g_instances.size() || !g_instances[id]) return fail("mgx_instance_destroy: no instance %d (instance 0 is permanent)", id);
+    victim = g_instances[id];
+    g_instances[id] = nullptr;
+  }
+  State *mine = Sp;
+  Sp = victim;
+  mgx_clean();
+  Sp = (mine == victim) ? &S0 : mine;
+  delete victim;
+  return 0;
+}
 
 const char *mgx_last_error(void) { return S.err.c_str(); }
 const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
@@ -949,7 +998,7 @@ int mgx_rccl_selftest(void) {
 }
 // which transport carries the neighbour traffic right now
 const char *mgx_transport(void) {
-  static std::string t;
+  std::string &t = S.transport_name;
   if (S.nranks <= 1 && !S.native_rccl) t = "none (one rank)";
   else {
     t = S.native_rccl ? std::string("RCCL, native (") + mgxr_library() + ")" : (S.ex ? "host callbacks (mgx_set_comm)" : "none");
@@ -1337,15 +1386,15 @@ int mgx_print_tictoc(const char *path) {
   // the reference's formats (mg_tictoc.f90:128-150): t22 + A10, (x,I9) per level; per timer (x,A20), (x,E9.3) total and per level, then
   // the call counts under them -- byte for byte what flang writes (tests/golden/ref_tictoc.txt), E9.3 in Fortran's 0.dddE+ee form
   fprintf(f, "%21s%10s", "", "Total");
-  for (int l = 1; l <= tt_nblev; l++) fprintf(f, " %9d", l);
+  for (int l = 1; l <= S.tt_nblev; l++) fprintf(f, " %9d", l);
   fprintf(f, "\n");
-  for (size_t q = 0; q < tt_names.size(); q++) {
+  for (size_t q = 0; q < S.tt_names.size(); q++) {
     double tot = 0; long long nc = 0;
-    for (int l = 0; l < tt_nblev; l++) { tot += tt_time[l][q]; nc += tt_calls[l][q]; }
-    fprintf(f, " %20s %s", tt_names[q].c_str(), fortran_e3(tot, 9).c_str());
-    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %s", fortran_e3(tt_time[l][q], 9).c_str());
+    for (int l = 0; l < S.tt_nblev; l++) { tot += S.tt_time[l][q]; nc += S.tt_calls[l][q]; }
+    fprintf(f, " %20s %s", S.tt_names[q].c_str(), fortran_e3(tot, 9).c_str());
+    for (int l = 0; l < S.tt_nblev; l++) fprintf(f, " %s", fortran_e3(S.tt_time[l][q], 9).c_str());
     fprintf(f, "\n%21s %9lld", "", nc);
-    for (int l = 0; l < tt_nblev; l++) fprintf(f, " %9lld", tt_calls[l][q]);
+    for (int l = 0; l < S.tt_nblev; l++) fprintf(f, " %9lld", S.tt_calls[l][q]);
     fprintf(f, "\n");
   }
   fclose(f);
@@ -1489,6 +1538,33 @@ int mgx_p2p_prepare(void *handles_out) {
 }
 
 int mgx_p2p_handle_bytes(void) { return (int)(2 * sizeof(hipIpcMemHandle_t)); }
+
+// the receive slab and the flag page of THIS instance (after mgx_p2p_prepare), for ranks that live in the same process
+int mgx_p2p_local_pointers(void **slab, void **flags) {
+  NEED_INIT();
+  if (!S.p2p_slab) return fail("mgx_p2p_local_pointers: call mgx_p2p_prepare first");
+  *slab = S.p2p_slab; *flags = S.p2p_flags;
+  return 0;
+}
+
+// mgx_p2p_connect for ranks whose buffers are directly addressable (other instances of this process; memory the caller mapped
+// itself): slabs[r], flags[r] = what rank r's mgx_p2p_local_pointers returned.  Nothing is opened and nothing is closed later.
+int mgx_p2p_connect_pointers(void *const *slabs, void *const *flags, int nranks) {
+  NEED_INIT();
+  if (!S.p2p_slab) return fail("mgx_p2p_connect_pointers: call mgx_p2p_prepare first");
+  if (nranks != S.nranks) return fail("mgx_p2p_connect_pointers: %d pointer pairs for %d ranks", nranks, S.nranks);
+  if ((int)S.lev.size() * 16 > 1024 || (int)S.lev.size() * 8 > 3072) return fail("mgx_p2p_connect_pointers: too many levels");
+  S.peer_slab.assign(nranks, nullptr); S.peer_flags.assign(nranks, nullptr);
+  for (int r = 0; r < nranks; r++) { S.peer_slab[r] = (double *)slabs[r]; S.peer_flags[r] = (unsigned long long *)flags[r]; }
+  S.peer_slab[S.rank] = S.p2p_slab; S.peer_flags[S.rank] = S.p2p_flags;
+  for (auto &L : S.lev) {
+    for (int d = 0; d < 8; d++) if (L.neighb[d] >= 0 && !S.peer_slab[L.neighb[d]]) return fail("mgx_p2p_connect_pointers: no buffers for neighbour rank %d", L.neighb[d]);
+    if (L.gather) for (int q = 0; q < L.ngroup; q++) if (!S.peer_slab[L.group[q]]) return fail("mgx_p2p_connect_pointers: no buffers for group member %d", L.group[q]);
+  }
+  S.p2p_borrowed = true;
+  S.p2p_ready = true; S.p2p_on = true;
+  return 0;
+}
 
 int mgx_p2p_connect(const void *all_handles, int nranks) {
   NEED_INIT();

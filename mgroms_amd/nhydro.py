@@ -4,6 +4,7 @@ meaning.  Arrays follow the reference's Fortran shapes; pass numpy arrays whose 
 Fortran index, i.e. a field p(nz,0:ny+1,0:nx+1) is a numpy array of shape (nx+2, ny+2, nz).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -11,7 +12,14 @@ from ._lib import Params, MgxError, lib, check  # noqa: F401
 
 FIELD = {"p": 0, "b": 1, "r": 2, "cA": 3, "dx": 4, "dy": 5, "zeta": 6, "h": 7, "zr": 8, "zw": 9, "cw": 10, "rmask": 14}
 _DP = C.POINTER(C.c_double)
-_state = {"dims": None}
+
+
+class _PerThread(threading.local):
+    """dims of the instance the calling thread drives (include/mgx.h: the instance selection is per thread as well)"""
+    dims = None
+
+
+_state = _PerThread()
 
 
 def _dp(a):
@@ -64,14 +72,14 @@ def nhydro_init(nx, ny, nz, npxg=1, npyg=1, rank=0, params=None, comm=None):
     if comm is not None:
         comm.install()
     check(lib().mgx_init(nx, ny, nz, npxg, npyg, rank, None if params is None else C.byref(params)))
-    _state["dims"] = (nx, ny, nz)
+    _state.dims = (nx, ny, nz)
     if comm is not None and npxg * npyg > 1:
         comm.after_init()
 
 
 def nhydro_matrices(dx, dy, zeta, h, rmask=None, hc=0.0, theta_b=0.0, theta_s=0.0):
     """nhydro_matrices (nhydro.f90:36): 2-D arrays are (0:ny+1,0:nx+1) in Fortran = numpy shape (nx+2, ny+2)."""
-    nx, ny, _ = _state["dims"]
+    nx, ny, _ = _state.dims
     sh = (nx + 2, ny + 2)
     dx, dy, zeta, h = (_f64(a, sh, n) for a, n in ((dx, "dx"), (dy, "dy"), (zeta, "zeta"), (h, "h")))
     rm = None if rmask is None else _f64(rmask, sh, "rmask")
@@ -79,7 +87,7 @@ def nhydro_matrices(dx, dy, zeta, h, rmask=None, hc=0.0, theta_b=0.0, theta_s=0.
 
 
 def _uvw(u, v, w):
-    nx, ny, nz = _state["dims"]
+    nx, ny, nz = _state.dims
     for a, sh, n in ((u, (nz, ny + 2, nx + 1), "u"), (v, (nz, ny + 1, nx + 2), "v"), (w, (nz + 1, ny + 2, nx + 2), "w")):
         if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == sh):
             raise ValueError(f"{n}: need a C-contiguous float64 array of shape {sh} (updated in place)")
@@ -89,7 +97,7 @@ def _mask(rmask):
     """rmaska of the call, (0:ny+1,0:nx+1) in Fortran = numpy (nx+2, ny+2); None = the mask of nhydro_matrices / all ones."""
     if rmask is None:
         return None, None
-    nx, ny, _ = _state["dims"]
+    nx, ny, _ = _state.dims
     rm = _f64(rmask, (nx + 2, ny + 2), "rmask")
     return rm, _dp(rm)
 
@@ -103,7 +111,7 @@ def nhydro_solve(u, v, w, rmask=None):
 
 def nhydro_solve_device(u, v, w, rmask=None):
     """nhydro_solve on torch CUDA tensors (float64, contiguous, shapes as nhydro_solve; rmask (nx+2, ny+2)): no host round trip."""
-    nx, ny, nz = _state["dims"]
+    nx, ny, nz = _state.dims
     for a, sh, n in ((u, (nz, ny + 2, nx + 1), "u"), (v, (nz, ny + 1, nx + 2), "v"), (w, (nz + 1, ny + 2, nx + 2), "w")):
         if not (a.is_cuda and a.is_contiguous() and tuple(a.shape) == sh and str(a.dtype) == "torch.float64"):
             raise ValueError(f"{n}: need a contiguous float64 CUDA tensor of shape {sh}")
@@ -129,7 +137,7 @@ def compute_rhs(u, v, w, rmask=None):
 
 def nhydro_clean():
     lib().mgx_clean()
-    _state["dims"] = None
+    _state.dims = None
 
 
 # ---- mg_solvers / mg_relax / mg_intergrids ------------------------------------------------------

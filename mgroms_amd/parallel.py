@@ -295,6 +295,137 @@ class Comm:
         self.p2p_active = bool(on)
 
 
+class ThreadWorld:
+    """Shared mailbox of `world` ranks that run as THREADS of one process, each driving its own libmgx.so instance
+    (include/mgx.h: mgx_instance_*) on its own HIP stream of the one device.  What MPI_COMM_WORLD is to the reference's ranks."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world)}    # messages a -> b
+        self.ack = {(a, b): queue.Queue() for a in range(world) for b in range(world)}  # b has copied a's message
+        self.scal = [None] * world
+        self.slab = [None] * world
+        self.flags = [None] * world
+        self.votes = [1] * world
+
+
+class ThreadComm:
+    """mgx_set_comm hooks between thread-ranks of one process (the reference's MPI layer, mg_mpi_exchange.f90:504-718,1555-1571,
+    mg_gather.f90:126, as device-to-device copies): a sender synchronises its stream and posts the device pointer, the receiver
+    copies on its own stream and acknowledges.  Same interface as Comm (install / after_init / set_p2p / transport)."""
+    TIMEOUT = 40.0
+
+    def __init__(self, tw, rank, p2p=True):
+        self.tw, self.rank, self.world, self.p2p = tw, rank, tw.world, bool(p2p)
+        self.p2p_active, self.p2p_error = False, None
+        self.native_active, self.native_error = False, "thread ranks share one device"
+        self.last_error = None
+        self._ex, self._ar, self._ag = EXCHANGE_FN(self._exchange), ALLREDUCE_FN(self._allreduce), ALLGATHER_FN(self._allgather)
+
+    @staticmethod
+    def _t(ptr, count):
+        return torch.as_tensor(_DevPtr(ptr, count), device="cuda")
+
+    def _move(self, sends, recvs):
+        """sends: [(ptr, count, peer)], recvs: [(ptr, count, peer)]"""
+        torch.cuda.current_stream().synchronize()          # my send buffers are complete
+        for ptr, cnt, peer in sends:
+            self.tw.q[(self.rank, peer)].put((int(ptr), int(cnt)))
+        for ptr, cnt, peer in recvs:
+            sp, sc = self.tw.q[(peer, self.rank)].get(timeout=self.TIMEOUT)
+            if sc != cnt:
+                raise RuntimeError(f"rank {self.rank}: message of {sc} doubles from rank {peer}, expected {cnt}")
+            self._t(ptr, cnt).copy_(self._t(sp, sc))
+        torch.cuda.current_stream().synchronize()          # the copies are done: the senders may reuse their buffers
+        for _, _, peer in recvs:
+            self.tw.ack[(peer, self.rank)].put(1)
+        for _, _, peer in sends:
+            self.tw.ack[(self.rank, peer)].get(timeout=self.TIMEOUT)
+
+    def _exchange(self, ctx, n, peer, sendbuf, recvbuf, count):
+        try:
+            self._move([(sendbuf[q], count[q], int(peer[q])) for q in range(n)], [(recvbuf[q], count[q], int(peer[q])) for q in range(n)])
+            return 0
+        except Exception as e:
+            self.last_error = e
+            return 1
+
+    def _allreduce(self, ctx, buf, n):
+        try:
+            t = self._t(buf, n)
+            self.tw.scal[self.rank] = t.cpu().numpy().copy()
+            self.tw.barrier.wait(self.TIMEOUT)
+            tot = self.tw.scal[0].copy()
+            for r in range(1, self.world):             # rank order on every rank: the same bits everywhere
+                tot = tot + self.tw.scal[r]
+            self.tw.barrier.wait(self.TIMEOUT)
+            t.copy_(torch.from_numpy(tot))
+            torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:
+            self.last_error = e
+            return 1
+
+    def _allgather(self, ctx, group, ng, sendbuf, recvbuf, count):
+        try:
+            members = [int(group[q]) for q in range(ng)]
+            me = members.index(self.rank)
+            self._t(int(recvbuf) + 8 * me * count, count).copy_(self._t(sendbuf, count))
+            self._move([(sendbuf, count, m) for q, m in enumerate(members) if q != me],
+                       [(int(recvbuf) + 8 * q * count, count, m) for q, m in enumerate(members) if q != me])
+            return 0
+        except Exception as e:
+            self.last_error = e
+            return 1
+
+    def install(self):
+        from ._lib import check, lib
+        check(lib().mgx_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        check(lib().mgx_set_comm(self._ex, self._ar, self._ag, None))
+
+    def _agree(self, flag):
+        self.tw.votes[self.rank] = 1 if flag else 0
+        self.tw.barrier.wait(self.TIMEOUT)
+        ok = all(self.tw.votes)
+        self.tw.barrier.wait(self.TIMEOUT)
+        return ok
+
+    def after_init(self):
+        """collective over the thread-ranks, after mgx_init: connect the peer-to-peer pushes through plain pointers"""
+        from ._lib import lib
+        if not self.p2p:
+            return
+        L = lib()
+        blob = C.create_string_buffer(L.mgx_p2p_handle_bytes())
+        slab, flags = C.c_void_p(), C.c_void_p()
+        rc = L.mgx_p2p_prepare(blob) or L.mgx_p2p_local_pointers(C.byref(slab), C.byref(flags))
+        self.tw.slab[self.rank], self.tw.flags[self.rank] = slab.value, flags.value
+        if not self._agree(rc == 0):
+            self.p2p_error = L.mgx_last_error().decode() if rc else "a peer could not allocate its halo buffers"
+            return
+        a = (C.c_void_p * self.world)(*self.tw.slab)
+        b = (C.c_void_p * self.world)(*self.tw.flags)
+        rc = L.mgx_p2p_connect_pointers(a, b, self.world)
+        self.p2p_active = self._agree(rc == 0)
+        if not self.p2p_active:
+            self.p2p_error = L.mgx_last_error().decode() if rc else "a peer could not connect"
+            L.mgx_set_option(b"p2p", 0)
+
+    def set_p2p(self, on):
+        from ._lib import check, lib
+        self.tw.barrier.wait(self.TIMEOUT)   # between exchanges, all ranks together
+        check(lib().mgx_set_option(b"p2p", 1 if on else 0))
+        self.p2p_active = bool(on)
+        self.tw.barrier.wait(self.TIMEOUT)
+
+    def transport(self):
+        from ._lib import lib
+        return lib().mgx_transport().decode()
+
+
 def process_grid(world):
     """npx x npy used by bench.py for 1/2/4/8 GPUs (the reference's power-of-two cartesian grid, assumptions:1-6)."""
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2), 16: (4, 4)}[world]

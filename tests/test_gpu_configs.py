@@ -201,6 +201,30 @@ def test_config3_vcycle_512x512x64_bitwise(mg, golden):
     o.close()
 
 
+# ---- BASELINE config 5: seamount 2048x2048x128 on 4x2 -> the local block 512x1024x128 of one GPU ------------------------------
+def test_config5_vcycle_512x1024x128_bitwise(mg):
+    """Config 5's per-GPU block (2048/4 x 2048/2 x 128) as a one-rank problem: nx /= ny, nz = 128 (k_relax_tall at full plane
+    width, the 7-level hierarchy 512x1024x128 -> 8x16x2 of SURVEY 8(a14)), one FC Vcycle(1) bit for bit (b, p, r) against the
+    oracle on 4x4 emulated ranks, like config 3.  The 4x2 process grid itself, with the gather chain, is
+    tests/test_gpu_multirank.py::test_config5_4x2_ranks_in_one_process."""
+    _gpu(mg, 512, 1024, 128, relax_method="FC")
+    assert mg.nlevs() == 7
+    b_gpu = mg.grid(1).b
+    mg.Vcycle(1)
+    res = mg.compute_residual(1)
+    p, r = mg.grid(1).p, mg.grid(1).r
+    mg.nhydro_clean()
+    o = _oracle(512, 1024, 128, 4, 4, relax_method="FC")
+    assert o.nlevs == 7
+    assert _blocks_equal(b_gpu, o, "b", 4, 4) == []
+    o.vcycle(1)
+    reso = o.residual(1)
+    assert _blocks_equal(p, o, "p", 4, 4) == []
+    assert _blocks_equal(r, o, "r", 4, 4) == []
+    assert abs(res - reso) <= 1e-12 * reso
+    o.close()
+
+
 @pytest.mark.parametrize("nz", [64, 128])
 def test_level1_red_black_two_waves_per_block(mg, nz):
     """The level-1 kernels with TWO waves per workgroup (512 planes x 4 j-chunks = 2048 waves: red-black at 512x512; the LDS slices of

@@ -58,6 +58,27 @@ def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
         assert f"rank {r} ok" in out
 
 
+@pytest.mark.parametrize("npx,npy,nx,ny,nz,nsmall", [
+    (2, 2, 16, 16, 8, 8),      # the thread-rank machinery on a case the process-per-rank suite covers as well
+    (4, 2, 16, 16, 128, 16),   # BASELINE config 5's process grid: 8 ranks, nz = 128, nsmall = 16 -> a 2x2 gather, then a 2x1 gather
+    (4, 2, 32, 32, 16, 8),     # 4x2 with the gather on the last level only (2x1 after 2x2 ranks were halved once)
+])
+def test_config5_4x2_ranks_in_one_process(npx, npy, nx, ny, nz, nsmall):
+    """BASELINE config 5 asks for a 4x2 decomposition with the coarse-grid gather (nsmall = 16).  The test box
+    admits at most 6 processes on its GPU, so the 8 ranks run as 8 THREADS of one process, each on its own libmgx.so instance
+    and HIP stream (tests/_gpu_thread_ranks.py): the kernels, neighbour tables (incl. the four corner neighbours), gather
+    groups (mg_grids.f90:702-718: 2x2 families, then 2x1) and both transports are the ones a process-per-GPU run uses; only the
+    hipIpc mapping of the receive slabs is replaced by plain pointers.  Every rank's p (all levels), b, cA, zr, h bit for bit
+    against the oracle's emulated ranks."""
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_gpu_thread_ranks.py")] + [str(a) for a in (npx, npy, nx, ny, nz, nsmall)],
+                         capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-3000:]
+    for r in range(npx * npy):
+        assert f"rank {r} ok" in out.stdout
+    if (npx, npy, nz) == (4, 2, 128):
+        assert "gathered_levels=[2, 3]" in out.stdout, out.stdout
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` from a bare shell (no launcher): bench.py starts its own ranks before touching the GPU.
     Rehearsed here with both ranks on the one GPU of the box (--backend gloo: host-staged callbacks + hipIpc pushes)."""

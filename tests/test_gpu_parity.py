@@ -466,9 +466,9 @@ def test_warm_start_and_tictoc(mg, tmp_path):
     assert shape(ref[0])[:41] == shape(mine[0])[:41]
     tl, cl = shape(ref[1]), shape(ref[2])   # a timer line and its call-count line, three levels wide in the fixture
     for k in range(1, len(mine), 2):
-        assert shape(mine[k])[22:22 + 10] == tl[22:32] and len(mine[k]) == 21 + 10 * (nl + 1), mine[k]        # " 0.###E~##" columns
+        assert shape(mine[k])[21:31] == tl[21:31] == " #.###E~##" and len(mine[k]) == 21 + 10 * (nl + 1), mine[k]
         assert re.fullmatch(r" {21}( +#+){%d}" % (nl + 1), shape(mine[k + 1])) and len(mine[k + 1]) == len(mine[k]), mine[k + 1]
-        assert all(shape(mine[k])[c:c + 10] == tl[22:32] for c in range(21, len(mine[k]), 10))
+        assert all(shape(mine[k])[c:c + 10] == tl[21:31] for c in range(21, len(mine[k]), 10)), mine[k]
     assert cl.startswith(" " * 21)
 
 
