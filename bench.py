@@ -27,7 +27,8 @@ SMOOTHER_BYTES_PER_CELL = 88  # cA 64 + b 8 + p read 8 + p write 8,
 PGRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 # oracle/mgoracle.c against the real reference (flang -O2 + MPICH) on the SAME 8 cores of the development container, 4x2
 # ranks, seamount 512x512x64: reference time / port time.  Relates the port's number on the
-# GPU box's host cores back to the reference, which cannot travel.
+# GPU box's host cores back to the reference, which cannot travel.  The port's side of each ratio is re-measured by
+# scripts/cpu_calibration.py (run in the development container); the reference's side is BASELINE.md's recorded figure.
 CALIBRATION = {"host": "development container, 8 cores, 4x2 (emulated) ranks, seamount 512x512x64",
                "FC": {"solve_iteration": 0.66 / 0.711, "level1_sweep": 75.0 / 92.8, "level1_residual": 36.0 / 48.3},
                "RB": {"solve_iteration": 0.68 / 0.750, "level1_sweep": 67.0 / 75.9, "level1_residual": 44.0 / 42.7}}
@@ -93,7 +94,8 @@ def main():
     ap.add_argument("--no-p2p", action="store_true", help="N>1: halos through the torch.distributed callback only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
-    ap.add_argument("--no-native-rccl", action="store_true", help="N>1: torch.distributed callbacks instead of libmgx.so's own RCCL communicator")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="N>1: libmgx.so's own RCCL communicator instead of the torch.distributed callbacks (opt-in: never run on more than one GPU yet)")
     args = ap.parse_args()
     if args.gpus not in PGRID:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
@@ -119,7 +121,7 @@ def main():
         else:
             dist.init_process_group("gloo")
         from mgroms_amd.parallel import Comm
-        comm = Comm(p2p=not args.no_p2p, native=(args.backend == "nccl" and not args.no_native_rccl))
+        comm = Comm(p2p=not args.no_p2p, native=(args.backend == "nccl" and args.native_rccl))
 
     import mgroms_amd as mg
     from mgroms_amd import nhydro
@@ -241,7 +243,9 @@ def main():
     # the process, in passes of their own), so the figure is read from the committed capture of THIS command
     # (profiles/r02_pmc_traffic.json, made by scripts/pmc_summary.py) and labelled as such
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    pmc = pmcs[-1] if pmcs else ""
     # the level-1 colour pass of the headline workload (nz = 64, level too large for the Infinity Cache); other --size values run
     # other kernels (k_relax_ks for nz <= 32 when a colour has <= 512 waves, k_relax_tall for nz = 128)
     kname = f"k_relax_nz<{nz}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>" if nz == 64 else f"level-1 colour pass, nz={nz}"
@@ -250,8 +254,8 @@ def main():
             pj = json.load(open(pmc))
             if pj.get("cells") == cells and kname in pj["kernels"]:
                 traffic = pj["kernels"][kname]["hbm_bytes"]
-                traffic_src = ("NOT measured in this run: profiles/r02_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                               "command, FETCH x2 (the guide's gfx950 correction, calibrated on an 8-B/lane read of known size)")
+                traffic_src = (f"NOT measured in this run: profiles/{os.path.basename(pmc)}, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                               "command (scripts/capture_profiles.sh), FETCH x2 (the guide's gfx950 correction, calibrated on an 8-B/lane read of known size)")
         except Exception:
             pass
     out = None
@@ -269,6 +273,11 @@ def main():
                        "transport_check": transport_check, "nsmall": (8 if world == 1 else args.nsmall)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # two labelled rates: effective = algorithmic bytes / time (= achieved, the contract's figure); measured = counter
+                         # traffic / time, what the HBM interface actually carried (lower: the pass streams 7 of the 11 arrays the yardstick counts)
+                         "effective_GBs": achieved,
+                         "measured_GBs": (None if traffic is None else traffic / (sweep_ms / ncol * 1e-3) / 1e9),
+                         "measured_frac": (None if traffic is None else traffic / (sweep_ms / ncol * 1e-3) / 1e9 / HBM_PEAK_GBS),
                          "kernel": kname + " (level-1 colour pass)",
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "traffic_note": "counter traffic below the algorithmic bytes: SURVEY 8(d)'s 88 B/cell counts 11 streamed arrays; the pass "

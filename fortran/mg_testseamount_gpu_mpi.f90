@@ -79,6 +79,7 @@ program mg_testseamount_gpu_mpi
         h(j,i) = Htot*(1._8 - 0.5_8*exp(-(x-x0)**2._8/(Lx/5._8)**2._8 - (y-y0)**2._8/(Ly/5._8)**2._8))
      enddo
   enddo
+  if (bmask) call fill_halo_2D_bmask(1, rmask)   ! mask the physical boundaries (mg_testseamount.f90, fill_halo_2D_bmask)
   call nhydro_matrices(dx, dy, zeta, h, rmask, hc, theta_b, theta_s)
 
   allocate(u(1:nx+1,0:ny+1,1:nz), v(0:nx+1,1:ny+1,1:nz), w(0:nx+1,0:ny+1,0:nz))

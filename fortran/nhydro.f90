@@ -12,6 +12,7 @@ module nhydro
   implicit none
   integer(kind=4), parameter :: rp = 8, ip = 4
   integer(kind=4) :: nhydro_rank = 0   !< set before nhydro_init when the caller has an MPI rank
+  logical :: bmask = .false.           !< namelist member, as `use mg_namelist` gives the reference's drivers; valid after nhydro_init
 
   interface
      integer(c_int) function mgx_init(nx, ny, nz, npx, npy, rank, par) bind(C, name='mgx_init')
@@ -42,6 +43,16 @@ module nhydro
        integer(c_int), value :: lev, field
        real(c_double), intent(out) :: host(*)
      end function mgx_get_field
+     integer(c_int) function mgx_get_option(name, value) bind(C, name='mgx_get_option')
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_int), intent(out) :: value
+     end function mgx_get_option
+     integer(c_int) function mgx_level_info(lev, info) bind(C, name='mgx_level_info')
+       import :: c_int
+       integer(c_int), value :: lev
+       integer(c_int), intent(out) :: info(18)
+     end function mgx_level_info
      type(c_ptr) function mgx_last_error() bind(C, name='mgx_last_error')
        import :: c_ptr
      end function mgx_last_error
@@ -62,8 +73,28 @@ contains
   subroutine nhydro_init(nx, ny, nz, npxg, npyg)
     integer(kind=ip), intent(in) :: nx, ny, nz
     integer(kind=ip), intent(in) :: npxg, npyg
+    integer(c_int) :: ib
     call mgx_check(mgx_init(nx, ny, nz, npxg, npyg, nhydro_rank, c_null_ptr), 'nhydro_init')
+    call mgx_check(mgx_get_option('bmask'//c_null_char, ib), 'nhydro_init')
+    bmask = ib /= 0
   end subroutine nhydro_init
+
+  !--------------------------------------------------------------  (mg_mpi_exchange.f90:357-391)
+  !> fill_halo_2D_bmask(1, a2D): zero the halo line of every side without a neighbour (what the reference's drivers call on rmask
+  !> before nhydro_matrices when bmask, mg_testseamount.f90)
+  subroutine fill_halo_2D_bmask(lev, a2D)
+    integer(kind=ip), intent(in) :: lev
+    real(kind=rp), dimension(:,:), pointer, intent(inout) :: a2D
+    integer(c_int) :: info(18)
+    integer(kind=ip) :: nx, ny, j0, i0
+    call mgx_check(mgx_level_info(lev, info), 'fill_halo_2D_bmask')
+    j0 = lbound(a2D, 1); i0 = lbound(a2D, 2)
+    ny = size(a2D, dim=1) - 2; nx = size(a2D, dim=2) - 2
+    if (info(11) < 0) a2D(j0, :) = 0._rp            ! south
+    if (info(12) < 0) a2D(:, i0+nx+1) = 0._rp       ! east
+    if (info(13) < 0) a2D(j0+ny+1, :) = 0._rp       ! north
+    if (info(14) < 0) a2D(:, i0) = 0._rp            ! west
+  end subroutine fill_halo_2D_bmask
 
   !--------------------------------------------------------------  (nhydro.f90:36-50)
   subroutine nhydro_matrices(dx, dy, zeta, h, rmask, hc, theta_b, theta_s)
@@ -88,8 +119,10 @@ contains
     real(kind=rp), dimension(1:nx+1,0:ny+1,1:nz), target, intent(inout) :: ua
     real(kind=rp), dimension(0:nx+1,1:ny+1,1:nz), target, intent(inout) :: va
     real(kind=rp), dimension(0:nx+1,0:ny+1,0:nz), target, intent(inout) :: wa
-    ! rmaska: the memory the caller allocated as rmask(0:ny+1,0:nx+1) (mg_testseamount.f90:97,185); the reference indexes
-    ! it rmask(j,i) after `rmask => rmaska` (nhydro.f90:72, mg_compute_rhs.f90:61,110), and so does the library
+    ! rmaska: the memory the caller allocated as rmask(0:ny+1,0:nx+1) and filled as rmask(j,i) (mg_testseamount.f90:97,185).  The
+    ! library reads it in THAT layout (element (j,i) at j+(ny+2)*i).  The reference, after `rmask => rmaska` with the bounds declared
+    ! above, reads rmask(j,i) at j+(nx+2)*i (nhydro.f90:72, mg_compute_rhs.f90:61,110): the same element for square blocks or an
+    ! all-ones mask -- the cases it is run on -- and a different one otherwise.  Deliberate: the drivers' layout is the intent.
     call mgx_check(mgx_solve(ua, va, wa, c_loc(rmaska)), 'nhydro_solve')
   end subroutine nhydro_solve
 

@@ -67,7 +67,9 @@ int mgx_matrices(const double *dx, const double *dy, const double *zeta, const d
  * rmask = the mask of THIS call (rmaska, nhydro.f90:56,72): the same memory layout as in mgx_matrices, (0:ny+1,0:nx+1)
  * with j fastest -- what the reference's drivers allocate (mg_testseamount.f90:97) and what compute_rhs / correct_uvw
  * index as rmask(j,i) (mg_compute_rhs.f90:61,110; the explicit-shape dummy of nhydro_solve declares it (0:nx+1,0:ny+1),
- * which is the same memory for the square blocks the reference is run on).  As in the reference it multiplies the w
+ * which is the same memory for the square blocks the reference is run on; on a non-square block with a non-trivial mask the
+ * reference's own indexing reads element j+(nx+2)*i of an array its drivers fill at j+(ny+2)*i -- the library keeps the
+ * drivers' layout, deliberately).  As in the reference it multiplies the w
  * cross terms of compute_rhs whatever bmask says, and yields umask / vmask when bmask (mg_compute_rhs.f90:56-72,
  * mg_correct_uvw.f90:51-68).  NULL = the level-1 mask of mgx_matrices when bmask, else all ones. */
 int mgx_solve(double *u, double *v, double *w, const double *rmask);
@@ -154,12 +156,19 @@ int mgx_set_verbose(int level);
  * fine level's r as mg_intergrids.f90:218-226 does (dead state: compute_residual rewrites r before anything reads it; the
  * mgx_coarse2fine operator always stores it, and so do the cycles under "exact_halos"); "verbose"; "p2p" (see below); "rb_chain" (default 1) red-black with cmatrix='real' on a
  * single-rank level: the colour passes write the next sweep's k=1 snapshot themselves, 0 = one snapshot launch per pass;
+ * "c2f_skip" (default 1; MGX_C2F_NOSKIP=1 = 0): inside a cycle the prolongation before a four-colour relax does not update the
+ * (i odd, j odd) columns, which that relax's first colour overwrites without reading them (mg_relax.f90:212-216) -- the coupling is
+ * asserted by tests/test_gpu_parity.py::test_c2f_skip_is_invisible; 0 updates every column as the reference does;
  * "rb_exact" (default 0; environment MGX_RB_EXACT): relax_method='RB' with cmatrix='real' in the reference's SEQUENTIAL
  * order (mg_relax.f90:170-186: a column reads the same-colour k=1 diagonals of plane i-1 already updated, :271-276), one
  * launch per i-plane -- bit-identical to the reference loop, including its decomposition dependence, but launch-bound.
  * With 0 the colour pass is parallel and reads those four values as they were before the pass (the reference's own
  * results differ by 2.5e-6 between decompositions for the same reason; tolerance in DESIGN.md section 2). */
 int mgx_set_option(const char *name, int value);
+/* read back an option, or an integer / logical member of /nhparam/ as mgx_init took it from nh_namelist ("bmask", "nsmall",
+ * "solver_maxiter", "ns_coarsest", "ns_pre", "ns_post", "netcdf_output", "aggressive"): the reference's drivers read these module
+ * variables of mg_namelist directly (e.g. `if (bmask)`, mg_testseamount.f90) */
+int mgx_get_option(const char *name, int *value);
 /* print_tictoc (mg_tictoc.f90:114-153): timer table (seconds, calls per level) to `path` (NULL = "fort.10") */
 int mgx_print_tictoc(const char *path);
 

@@ -151,6 +151,7 @@ struct State {
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
+  int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
   std::string err, transport_name;
   // mg_tictoc.f90's module variables (subname, time, calls, nblev) + the HIP events still in flight
@@ -525,7 +526,7 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
   // returns true when the fused residual+restriction kernel took the job
   auto down = [&](const LevView *Cv, double *dst, Sides ph, double *zero) -> int {
     if (!with_residual) return 0;
-    if (!S.exact_halos && !dup_r) {
+    if (!S.exact_halos && !S.keep_r && !dup_r) {  // keep_r: the caller wants the reference's r, which the fused kernel never writes
       TicScope ts(lev, "residual_3D_8");
       if (mgxk_residual_restrict(S.stream, &F.v, Cv, dst, S.real, ph, zero)) { S.n_launch++; return 1; }
     }
@@ -607,7 +608,7 @@ int vcycle(int lev1) {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_post >= 1));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_post >= 1));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -621,7 +622,7 @@ int vcycle2(int lev1, int lev2) {
   }
   CHK(relax(lev2, S.par.ns_coarsest));
   for (int lev = lev2 - 1; lev >= lev1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_post >= 1));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_post >= 1));
     CHK(relax(lev, S.par.ns_post));
   }
   return 0;
@@ -635,7 +636,7 @@ int fcycle() {
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.method == M_FC && S.par.ns_pre >= 1));
+    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_pre >= 1));
     CHK(vcycle(lev));
   }
   return 0;
@@ -871,6 +872,9 @@ void p2p_release() {
 // stream synchronise + the peer-to-peer error word (a neighbour that never raised its flag)
 int sync_stream() {
   HIPCHK(hipStreamSynchronize(S.stream));
+  // a kernel launch this thread issued since the last check was refused (launch configuration, LDS or register demand on this
+  // device / ROCm): the operator it belonged to did not run, so the fields are not what the caller thinks -- fail loudly
+  { hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail("a kernel launch was rejected: %s", hipGetErrorString(le)); }
   if (S.p2p_err && *S.p2p_err) {
     // a missed exchange leaves the per-level sequence numbers of the two neighbours apart for good: every later exchange would
     // time out as well (5 s each).  The pushes are switched off on this rank; the caller has to re-establish them collectively
@@ -893,6 +897,39 @@ int apply_params(const mgx_params &p) {
   if (S.linear && streq(p.restrict_type, "linear")) return fail("linear interp + linear restrict is not permitted");
   if (p.aggressive) return fail("aggressive=.true.: coarse2fine_aggressive is not available in the reference either (mg_intergrids.f90:243)");
   S.par = p;
+  return 0;
+}
+
+// A level-1 halo fill of a rank-coded field through the CURRENT neighbour transport (the hooks, or the pushes when they are on), all
+// eight directions: every halo cell must hold the value its owner encoded (mg_testhalo.f90:75-92 with positions, not just ranks).
+// Collective.  Leaves level-1 p zeroed.
+int halo_rank_coded_check(const char *who) {
+  Level &L = S.lev[0];
+  const int nx = L.nx, ny = L.ny, nz = L.nz;
+  const size_t n3 = (size_t)nz * (ny + 2) * (nx + 2);
+  std::vector<double> h(n3, -1.0);
+  auto at = [&](int k, int j, int i) -> size_t { return (size_t)k + (size_t)nz * ((size_t)j + (size_t)(ny + 2) * i); };
+  auto code = [&](int r, int k, int j, int i) { return 1.0e7 * (r + 1) + (double)at(k, j, i); };
+  for (int i = 1; i <= nx; i++) for (int j = 1; j <= ny; j++) for (int k = 0; k < nz; k++) h[at(k, j, i)] = code(S.rank, k, j, i);
+  HIPCHK(hipMemcpyAsync(S.ref_scratch, h.data(), n3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
+  mgxk_convert(S.stream, &L.v, L.v.p, S.ref_scratch, 1, 0, 0);
+  CHK(fill_halo_js(L, L.v.p));
+  mgxk_convert(S.stream, &L.v, L.v.p, S.ref_scratch, 1, 0, 1);
+  HIPCHK(hipMemcpyAsync(h.data(), S.ref_scratch, n3 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  CHK(sync_stream());
+  HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));
+  const int *nb = L.neighb;
+  // halo cell (j,i) of direction d is the owner's cell (js,is): S,E,N,W,SW,SE,NE,NW
+  for (int d = 0; d < 8; d++) {
+    if (nb[d] < 0) continue;
+    const bool south = (d == 0 || d == 4 || d == 5), north = (d == 2 || d == 6 || d == 7), east = (d == 1 || d == 5 || d == 6), west = (d == 3 || d == 4 || d == 7);
+    const int j0 = south ? 0 : (north ? ny + 1 : 1), j1 = south ? 0 : (north ? ny + 1 : ny);
+    const int i0 = west ? 0 : (east ? nx + 1 : 1), i1 = west ? 0 : (east ? nx + 1 : nx);
+    for (int i = i0; i <= i1; i++) for (int j = j0; j <= j1; j++) for (int k = 0; k < nz; k++) {
+      const int js = south ? ny : (north ? 1 : j), is = west ? nx : (east ? 1 : i);
+      if (h[at(k, j, i)] != code(nb[d], k, js, is)) return fail("%s: halo cell (k=%d,j=%d,i=%d) of direction %d does not hold rank %d's value", who, k + 1, j, i, d, nb[d]);
+    }
+  }
   return 0;
 }
 
@@ -961,9 +998,10 @@ int mgx_rccl_disconnect(void) {
   mgxr_disconnect();
   return 0;
 }
-// Collective self-test of the native transport (any world size, after mgx_init): an all-reduce of rank+1 and one grouped
-// exchange of rank-coded buffers with the next and the previous rank (with itself on one rank) through the same hooks the
-// halo fills use.  0 = every value arrived.
+// Collective self-test of the native transport (any world size, after mgx_init): one grouped exchange of rank-coded buffers with the
+// next and the previous rank (with itself on one rank), an all-reduce of rank+1, an all-gather inside groups of up to four ranks and a
+// level-1 halo fill of a position-coded field over all eight neighbour directions -- through the same hooks the solver uses.
+// 0 = every value arrived.  Level-1 p is zero afterwards.
 int mgx_rccl_selftest(void) {
   NEED_INIT();
   if (!S.native_rccl || !mgxr_connected()) return fail("mgx_rccl_selftest: the native RCCL transport is not connected");
@@ -994,6 +1032,23 @@ int mgx_rccl_selftest(void) {
   HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, sizeof(double), hipMemcpyDeviceToHost, S.stream));
   CHK(sync_stream());
   if (S.h_scalar[0] != 0.5 * n * (n + 1)) return fail("mgx_rccl_selftest: all-reduce gave %g, expected %g", S.h_scalar[0], 0.5 * n * (n + 1));
+  {  // all-gather leg (gather_3D's hook): groups of up to four consecutive ranks, the shape of the reference's colour groups
+    const int g0 = me / 4 * 4, ng = std::min(4, n - g0), gc = (int)std::min<size_t>(500, S.ref_scratch_n / 8);
+    int grp[4];
+    for (int q = 0; q < ng; q++) grp[q] = g0 + q;
+    std::vector<double> hs(gc), hr((size_t)gc * ng);
+    for (int t = 0; t < gc; t++) hs[t] = 7000.0 * me + t;
+    double *sb = S.ref_scratch, *rb = S.ref_scratch + gc;
+    HIPCHK(hipMemcpyAsync(sb, hs.data(), gc * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPCHK(hipMemsetAsync(rb, 0, (size_t)gc * ng * sizeof(double), S.stream));
+    HIPCHK(hipStreamSynchronize(S.stream));
+    if (S.ag(S.ctx, grp, ng, sb, rb, gc)) return fail("mgx_rccl_selftest: all-gather failed: %s", mgxr_last_error());
+    HIPCHK(hipMemcpyAsync(hr.data(), rb, (size_t)gc * ng * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    CHK(sync_stream());
+    for (int q = 0; q < ng; q++)
+      for (int t = 0; t < gc; t++) if (hr[(size_t)q * gc + t] != 7000.0 * grp[q] + t) return fail("mgx_rccl_selftest: all-gather slot %d holds wrong data (element %d)", q, t);
+  }
+  CHK(halo_rank_coded_check("mgx_rccl_selftest"));
   return 0;
 }
 // which transport carries the neighbour traffic right now
@@ -1086,11 +1141,11 @@ void mgx_clean(void) {
   for (void *q : S.allocs) (void)hipFree(q);
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1199,6 +1254,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(sync_stream());
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
+  if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
   if (getenv("MGX_TICTOC")) S.tictoc = 1;
   if (getenv("MGX_RB_EXACT")) S.rb_exact = atoi(getenv("MGX_RB_EXACT"));
@@ -1370,10 +1426,35 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "rb_chain")) S.rb_chain = value;
   else if (streq(name, "rb_exact")) S.rb_exact = value;
   else if (streq(name, "keep_r")) S.keep_r = value;
+  else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;
   }
+  else return fail("unknown option '%s'", name);
+  return 0;
+}
+
+// read back a namelist member (the reference's drivers `use mg_namelist` and read e.g. `bmask` directly) or an option
+int mgx_get_option(const char *name, int *value) {
+  if (!value) return fail("mgx_get_option: value is NULL");
+  if (streq(name, "bmask")) *value = S.par.bmask;
+  else if (streq(name, "nsmall")) *value = S.par.nsmall;
+  else if (streq(name, "solver_maxiter")) *value = S.par.solver_maxiter;
+  else if (streq(name, "ns_coarsest")) *value = S.par.ns_coarsest;
+  else if (streq(name, "ns_pre")) *value = S.par.ns_pre;
+  else if (streq(name, "ns_post")) *value = S.par.ns_post;
+  else if (streq(name, "netcdf_output")) *value = S.par.netcdf_output;
+  else if (streq(name, "aggressive")) *value = S.par.aggressive;
+  else if (streq(name, "warm_start")) *value = S.warm_start;
+  else if (streq(name, "tictoc")) *value = S.tictoc;
+  else if (streq(name, "exact_halos")) *value = S.exact_halos;
+  else if (streq(name, "verbose")) *value = S.verbose;
+  else if (streq(name, "rb_chain")) *value = S.rb_chain;
+  else if (streq(name, "rb_exact")) *value = S.rb_exact;
+  else if (streq(name, "keep_r")) *value = S.keep_r;
+  else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
+  else if (streq(name, "p2p")) *value = S.p2p_on ? 1 : 0;
   else return fail("unknown option '%s'", name);
   return 0;
 }

@@ -30,6 +30,11 @@ __device__ __forceinline__ void mirror_store(const LevView &L, double *__restric
   if (mE) { a[oE + c] = v; if (mS) a[oE + cS] = v; if (mN) a[oE + cN] = v; }
 }
 
+// A rejected launch (more LDS or registers than this ROCm / device grants) must not pass for a completed colour pass: wrappers that
+// have a generic fallback end in `return mgx_launched();` -- 0 = the launch was refused, nothing ran, the caller falls back; whatever
+// has no fallback is caught by the sticky-error check of the next synchronising call (sync_stream in mgx_api.cpp).
+static inline int mgx_launched() { return hipGetLastError() == hipSuccess ? 1 : 0; }
+
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
 
 // ---- switches and helpers shared by the smoother translation units ---------------------------------------------------

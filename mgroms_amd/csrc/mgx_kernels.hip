@@ -834,7 +834,8 @@ void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {
   Slots8 o;
   for (int q = 0; q < 8; q++) o.s[q] = L->cA[q];
   const size_t lds = (size_t)16 * (L->nz * 8 + 1) * sizeof(double);
-  (void)hipFuncSetAttribute((const void *)k_convert8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  // > 64 KB from nz = 64 on
+  // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
+  (void)hipFuncSetAttribute((const void *)k_convert8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_convert8, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
 }
 void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m) {

@@ -788,7 +788,7 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
                         else hipLaunchKernelGGL((k_relax_reg<2, false, 1024>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph, exact); }
       else { if (real) hipLaunchKernelGGL((k_relax_reg<4, true, 256>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph, exact);
              else hipLaunchKernelGGL((k_relax_reg<4, false, 256>), dim3(1), dim3(nth), bytes, st, *L, nsweeps, method, ph, exact); }
-      return 1;
+      return mgx_launched();
     }
   }
   {  // everything in LDS? (11 arrays of the compact level + the k=1 snapshot)
@@ -801,7 +801,7 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
                         else hipLaunchKernelGGL((k_relax_tiny<2, false>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph); }
       else { if (real) hipLaunchKernelGGL((k_relax_tiny<4, true>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph);
              else hipLaunchKernelGGL((k_relax_tiny<4, false>), dim3(1), dim3(ntht), bytes, st, *L, nsweeps, method, ph); }
-      return 1;
+      return mgx_launched();
     }
   }
   const int ncol = method == 2 ? (L->nx / 2) * (L->ny / 2) : L->nx * (L->ny / 2);
@@ -815,7 +815,7 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
   if (L->nz == 2 && ncol > 256 && ncol <= 1024) {
     if (real) hipLaunchKernelGGL((k_relax_small<2, true, 1024>), dim3(1), dim3(1024), 0, st, *L, nsweeps, method, ph, exact);
     else hipLaunchKernelGGL((k_relax_small<2, false, 1024>), dim3(1), dim3(1024), 0, st, *L, nsweeps, method, ph, exact);
-    return 1;
+    return mgx_launched();
   }
   if (ncol > 256 || L->nz > 8) return 0;
   // 32x32x8 (fifth level of an nz = 128 hierarchy), four colours: two colour-pair launches per sweep (k_relax_ks2, 5.9 us each) beat this
@@ -823,7 +823,7 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
   if (L->nz == 8 && method == 2 && L->zy != nullptr && ncol > 64 && L->ny / 2 <= WAVE) return 0;
   const int nth = ncol <= 64 ? 64 : 256;
 #define SMALL_CASE(NZV) case NZV: if (real) hipLaunchKernelGGL((k_relax_small<NZV, true, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph, exact); \
-                                  else hipLaunchKernelGGL((k_relax_small<NZV, false, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph, exact); return 1;
+                                  else hipLaunchKernelGGL((k_relax_small<NZV, false, 256>), dim3(1), dim3(nth), 0, st, *L, nsweeps, method, ph, exact); return mgx_launched();
   switch (L->nz) { SMALL_CASE(2) SMALL_CASE(4) SMALL_CASE(8) default: return 0; }
 #undef SMALL_CASE
 }

@@ -157,7 +157,7 @@ int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, i
 #define WAVE_CASE(NZV, NTV)                                                                                                   \
   { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);      \
     else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);          \
-    return 1; }
+    return mgx_launched(); }
   if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else WAVE_CASE(2, 256) }
   if (nblk <= WAVE) WAVE_CASE(4, 64) else WAVE_CASE(4, 256)
 #undef WAVE_CASE

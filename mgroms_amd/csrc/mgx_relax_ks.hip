@@ -278,7 +278,14 @@ __device__ __forceinline__ void ks_tridiag(const double *sh, const double *__res
   for (int k = 1; k <= NZ; k++) out[(k - 1) * stride + lane] = x[k - 1];
 }
 // store rows ka .. ka+R-1 of a column and the physical-boundary mirrors (mg_mpi_exchange.f90:509-537,552-597)
-template <int R>
+// WT: write-through stores (agent scope, `sc1`): the persistent kernel hands planes to other workgroups inside one launch
+template <bool WT> __device__ __forceinline__ void ks_st(double *q, const double v) {
+  if (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *q = v;
+}
+template <bool WT> __device__ __forceinline__ double ks_ld(const double *q) {
+  return WT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+}
+template <int R, bool WT = false>
 __device__ __forceinline__ void ks_store(const LevView &L, const long long o, const int c, const int i, const int j, const int ka, const int lane,
                                          const double *__restrict__ x, const int stride, const Sides ph) {
   double *__restrict__ p = L.p;
@@ -290,11 +297,47 @@ __device__ __forceinline__ void ks_store(const LevView &L, const long long o, co
     const int k = ka + r;
     const long long ro = (long long)(k - 1) * L.RS;
     const double v = x[(k - 1) * stride + lane];
-    p[o + ro + c] = v;
-    if (mS) p[o + ro + cS] = v;
-    if (mN) p[o + ro + cN] = v;
-    if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
-    if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
+    ks_st<WT>(p + o + ro + c, v);
+    if (mS) ks_st<WT>(p + o + ro + cS, v);
+    if (mN) ks_st<WT>(p + o + ro + cN, v);
+    if (mW) { ks_st<WT>(p + oW + ro + c, v); if (mS) ks_st<WT>(p + oW + ro + cS, v); if (mN) ks_st<WT>(p + oW + ro + cN, v); }
+    if (mE) { ks_st<WT>(p + oE + ro + c, v); if (mS) ks_st<WT>(p + oE + ro + cS, v); if (mN) ks_st<WT>(p + oE + ro + cN, v); }
+  }
+}
+// the two halves of ks_load for the persistent kernel: what no sweep changes (once per launch) ...
+template <int NZ, int R, bool REAL>
+__device__ __forceinline__ void ks_load_coef(KsRows<R> &q, const LevView &L, const long long o, const int c, const int jm, const int jp, const int ka, const bool diag) {
+  const long long RS = L.RS, om = o - L.plane, op = o + L.plane;
+  const double *__restrict__ b = L.b;
+  const double *__restrict__ a2 = L.cA[1], *__restrict__ a4 = L.cA[3], *__restrict__ a5 = L.cA[4], *__restrict__ a7 = L.cA[6],
+               *__restrict__ a8 = L.cA[7], *__restrict__ bet = L.bet, *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
+#pragma unroll
+  for (int r = 0; r < R + 2; r++) {
+    const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+    const long long ro = (long long)(k - 1) * RS;
+    q.zyo[r] = zy[o + ro + c]; q.zxo[r] = zx[o + ro + c];
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const long long ro = (long long)(ka + r - 1) * RS;
+    q.bb[r] = b[o + ro + c]; q.a4o[r] = a4[o + ro + c]; q.a7o[r] = a7[o + ro + c];
+    q.a4n[r] = a4[o + ro + jp]; q.a7n[r] = a7[op + ro + c];
+    q.zyjm[r] = zy[o + ro + jm]; q.zyjp[r] = zy[o + ro + jp]; q.zxim[r] = zx[om + ro + c]; q.zxip[r] = zx[op + ro + c];
+    q.oa2[r] = a2[o + ro + c]; q.obt[r] = bet[o + ro + c];
+  }
+  q.e1 = q.e2 = q.e3 = q.e4 = 0.0;
+  if (REAL && diag) { q.e1 = a5[o + c]; q.e2 = a5[op + jm]; q.e3 = a8[o + c]; q.e4 = a8[op + jp]; }
+}
+// ... and the i-1 / i+1 neighbours of p, which the neighbouring planes' workgroups rewrite every sweep
+template <int NZ, int R, bool WT>
+__device__ __forceinline__ void ks_load_p(KsRows<R> &q, const LevView &L, const long long o, const int c, const int ka) {
+  const long long RS = L.RS, om = o - L.plane, op = o + L.plane;
+  const double *p = L.p;
+#pragma unroll
+  for (int r = 0; r < R + 2; r++) {
+    const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+    const long long ro = (long long)(k - 1) * RS;
+    q.pim[r] = ks_ld<WT>(p + om + ro + c); q.pip[r] = ks_ld<WT>(p + op + ro + c);
   }
 }
 }  // namespace
@@ -362,6 +405,120 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks2(LevView L, int i0, int
   if (live) ks_store<R>(L, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A whole relax call -- nsweeps four-colour sweeps (mg_relax.f90:193-234) -- of a closed mid level in ONE launch.
+//
+// k_relax_ks2 above needs two launches per sweep (the odd planes' colours 1+2, then the even planes' colours 3+4): 10 dependent
+// launches per level visit at 9.2 us (128x128x16) / 5.9 us (64x64x8) each, of which the arithmetic is a small part -- the rest is the
+// kernel boundary, the ramp of a new grid and the re-load of coefficients that no sweep changes.  Here ONE workgroup per plane (odd and even
+// planes alike) stays resident for the whole call: it loads its columns' coefficients once into registers, then alternates with its
+// two neighbour planes through a per-plane progress counter in global memory:
+//     odd  plane i, sweep s : waits until planes i-1, i+1 have finished s phases, runs colours 1+2, publishes s+1
+//     even plane i, sweep s : waits until planes i-1, i+1 have finished s+1 phases, runs colours 3+4, publishes s+1
+// A plane's only inter-workgroup dependencies are its two neighbour planes (p at i-1 / i+1 incl. the k=1 diagonals); the waits
+// above order every read after the write it needs and every write after the last read of the value it replaces.
+// Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every load and store of p is an
+// agent-scope (sc1) access -- write-through stores, L1-bypassing loads --, each storing wave drains its stores (s_waitcnt vmcnt(0)),
+// the workgroup meets at a barrier, one lane stores the counter (sc1); the consumer polls it with one lane (sc1 loads, s_sleep
+// between polls) and releases its workgroup through a barrier.  FENCE = true swaps this for plain accesses between an agent-scope
+// release and acquire fence (the architecturally guaranteed form; A/B).  All nx workgroups must be resident together (<= 128 of
+// them, one per CU: 512 threads at up to 256 registers); the poll is bounded (2 s of the constant clock -> error word, reported by
+// the next synchronising call) so that a co-tenant that keeps a workgroup off the chip cannot hang the stream.
+// Same expressions in the same order as k_relax_ks2: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int NZ, int NW, bool REAL, bool FENCE>
+__global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps, Sides ph, unsigned int *done, unsigned int base, int *err) {
+  constexpr int R = NZ / NW;     // rows per wave
+  constexpr int XS = WAVE + 1;
+  constexpr bool WT = !FENCE;
+  __shared__ double sh[NZ * WAVE], sa2[NZ * WAVE], sbt[NZ * WAVE], xa[NZ * XS];
+  __shared__ int s_bail;
+  int i = blockIdx.x + 1;
+  if ((L.nx & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; i = xcd * (L.nx >> 3) + local + 1; }  // neighbour planes share an XCD (speed only)
+  const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int nh = L.ny >> 1;
+  const bool live = lane < nh, odd = (i & 1) != 0;
+  const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
+  const int ka = w * R + 1;
+  const int cA = L.HO + lane, jmA = L.EO + lane, jpA = jmA + 1;
+  const int cB = L.EO + lane + 1, jmB = L.HO + lane, jpB = jmB + 1;
+  const bool mW = ph.W && i == 1, mE = ph.E && i == L.nx;
+  const double *pr = L.p;
+  KsRows<R> A, B;
+  if (live) {
+    ks_load_coef<NZ, R, REAL>(A, L, o, cA, jmA, jpA, ka, w == 0);
+    ks_load_coef<NZ, R, REAL>(B, L, o, cB, jmB, jpB, ka, w == 0);
+  }
+  if (threadIdx.x == 0 && threadIdx.y == 0) s_bail = 0;
+  __syncthreads();
+  for (int s = 0; s < nsweeps; s++) {
+    if (!(odd && s == 0)) {  // the first phase of an odd plane reads what the previous launch left
+      if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned int need = base + (unsigned int)s + (odd ? 0u : 1u);
+        const long long t0 = wall_clock64();
+        for (;;) {
+          bool ok = true;
+          if (i > 1) ok = ok && (int)(__hip_atomic_load(done + i - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
+          if (i < L.nx) ok = ok && (int)(__hip_atomic_load(done + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
+          if (ok) break;
+          if (wall_clock64() - t0 > 200000000LL) { *err = 1; s_bail = 1; break; }  // 2 s at 100 MHz
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      }
+      __syncthreads();
+      if (s_bail) return;
+    }
+    double pjm[R + 2] = {}, pjp[R + 2] = {}, d1 = 0, d2 = 0, d3 = 0, d4 = 0, bd1 = 0, bd2 = 0, bd3 = 0, bd4 = 0;
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < R + 2; r++) {
+        const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+        pjm[r] = ks_ld<WT>(pr + o + (long long)(k - 1) * L.RS + jmA); pjp[r] = ks_ld<WT>(pr + o + (long long)(k - 1) * L.RS + jpA);
+      }
+      if (REAL && w == 0) {
+        d1 = ks_ld<WT>(pr + om + jpA); d2 = ks_ld<WT>(pr + op + jmA); d3 = ks_ld<WT>(pr + om + jmA); d4 = ks_ld<WT>(pr + op + jpA);
+        bd1 = ks_ld<WT>(pr + om + jpB); bd2 = ks_ld<WT>(pr + op + jmB); bd3 = ks_ld<WT>(pr + om + jmB); bd4 = ks_ld<WT>(pr + op + jpB);
+      }
+      ks_load_p<NZ, R, WT>(A, L, o, cA, ka);
+      ks_load_p<NZ, R, WT>(B, L, o, cB, ka);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) xa[(ka + r - 1) * XS + nh] = ks_ld<WT>(pr + o + (long long)(ka + r - 1) * L.RS + L.HO + nh);
+    }
+    if (live) ks_rhs<NZ, R, REAL>(A, pjm, pjp, d1, d2, d3, d4, ka, lane, sh, sa2, sbt);
+    __syncthreads();
+    if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, xa, XS);
+    __syncthreads();
+    if (live) {
+      ks_store<R, WT>(L, o, cA, i, 2 * lane + 1, ka, lane, xa, XS, ph);
+      double qjm[R + 2], qjp[R + 2];
+#pragma unroll
+      for (int r = 0; r < R + 2; r++) {
+        const int k = ka - 1 + r < 1 ? 1 : (ka - 1 + r > NZ ? NZ : ka - 1 + r);
+        qjm[r] = xa[(k - 1) * XS + lane]; qjp[r] = xa[(k - 1) * XS + lane + 1];
+      }
+      if (REAL && w == 0) {
+        if (mW) { bd1 = xa[lane + 1]; bd3 = xa[lane]; }
+        if (mE) { bd2 = xa[lane]; bd4 = xa[lane + 1]; }
+      }
+      ks_rhs<NZ, R, REAL>(B, qjm, qjp, bd1, bd2, bd3, bd4, ka, lane, sh, sa2, sbt);
+    }
+    __syncthreads();
+    if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, sh, WAVE);
+    __syncthreads();
+    if (live) ks_store<R, WT>(L, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
+    // publish: every storing wave drains its stores, the workgroup meets, one lane raises the plane's counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+      if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __hip_atomic_store(done + i, base + (unsigned int)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 extern "C" {
 
 // returns 1 when the pass was launched here (the level qualifies), 0 to let the row-by-row kernels take it
@@ -384,7 +541,7 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
     if (real && snap) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, true>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
     else if (real) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);     \
     else hipLaunchKernelGGL((k_relax_ks<NZV, NWV, false, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);              \
-    return 1;                                                                                                                    \
+    return mgx_launched();                                                                                                       \
   }
   if (L->nz == 64) {  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking
     static bool attr = false;
@@ -397,7 +554,7 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
     dim3 blk(WAVE, 8);
     if (real) hipLaunchKernelGGL((k_relax_ks<64, 8, true, false, 2>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
     else hipLaunchKernelGGL((k_relax_ks<64, 8, false, false, 2>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);
-    return 1;
+    return mgx_launched();
   }
   // measured (256x256x32 / 128x128x16, four-colour sweep): 8 waves 47.0 / 21.6 us, 4 waves 53.3 / 23.3, row by row 57.6 / 28.2
   if (L->nz == 32) { if (nw_env == 4) KS_LAUNCH(32, 4) else KS_LAUNCH(32, 8) }
@@ -416,7 +573,22 @@ int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, in
                      else hipLaunchKernelGGL((k_relax_ks2<16, 8, false>), grd, blk, 0, st, *L, i0, nplanes, ph); }
   else { if (real) hipLaunchKernelGGL((k_relax_ks2<8, 8, true>), grd, blk, 0, st, *L, i0, nplanes, ph);
          else hipLaunchKernelGGL((k_relax_ks2<8, 8, false>), grd, blk, 0, st, *L, i0, nplanes, ph); }
-  return 1;
+  return mgx_launched();
+}
+
+// all nsweeps four-colour sweeps of a closed mid level in one persistent launch (k_relax_ksp); returns 1 when launched.
+// done: nx + 2 progress counters of the level (zero at init), base: their common value now; the caller adds nsweeps afterwards.
+int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int real, Sides ph, unsigned int *done, unsigned int base, int *err) {
+  static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr || getenv("MGX_NO_KSP") != nullptr;
+  static const bool fence = getenv("MGX_KSP_FENCE") != nullptr;
+  if (off || nsweeps < 1 || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || (L->nx & 1) || L->ny / 2 > WAVE) return 0;
+  if ((L->nz != 16 && L->nz != 8) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
+  dim3 grd(L->nx), blk(WAVE, 8);
+#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, 8, RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err)
+  if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true); else KSP(16, true, false); } else { if (fence) KSP(16, false, true); else KSP(16, false, false); } }
+  else { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
+#undef KSP
+  return mgx_launched();
 }
 
 }  // extern "C"

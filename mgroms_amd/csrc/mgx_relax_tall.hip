@@ -268,7 +268,10 @@ extern "C" int mgxk_relax_nz128(hipStream_t st, const LevView *L, int i0, int is
 #define LAUNCH128_ONE(RV, SV, STV)                                                                                       \
   {                                                                                                                     \
     static bool attr = false;                                                                                           \
-    if (!attr) { (void)hipFuncSetAttribute((const void *)k_relax_tall<128, 64, RV, SV, 3, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * WAVE * (int)sizeof(double)); attr = true; } \
+    if (!attr) {                                                                                                        \
+      if (hipFuncSetAttribute((const void *)k_relax_tall<128, 64, RV, SV, 3, STV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * WAVE * (int)sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return 0; } \
+      attr = true;                                                                                                      \
+    }                                                                                                                   \
     hipLaunchKernelGGL((k_relax_tall<128, 64, RV, SV, 3, STV>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); \
   }
 #define LAUNCH128(STV)                                                                                                  \
@@ -280,6 +283,6 @@ extern "C" int mgxk_relax_nz128(hipStream_t st, const LevView *L, int i0, int is
   if (stream) LAUNCH128(true) else LAUNCH128(false)
 #undef LAUNCH128
 #undef LAUNCH128_ONE
-  return 1;
+  return mgx_launched();
 }
 

@@ -204,7 +204,7 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
   dim3 blk(WAVE, by), grd(gx * gy);
   if (real) hipLaunchKernelGGL((k_residual_restrict<true>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy);
   else hipLaunchKernelGGL((k_residual_restrict<false>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy);
-  return 1;
+  return mgx_launched();
 }
 
 }  // extern "C"

@@ -48,7 +48,10 @@ class Comm:
         self.staged = self.backend != "nccl"  # gloo moves host memory only
         # native: libmgx.so's own RCCL communicator serves the three hooks (no Python in the loop); torch.distributed only
         # carries the 128-byte bootstrap id.  Needs one GPU per rank, i.e. the real multi-GPU case (backend nccl).
-        self.native = (device == "cuda" and not self.staged) if native is None else bool(native)
+        # OPT-IN (default off): it has only ever run on a world of one rank (no multi-GPU node was available to this build); until a
+        # run on >= 2 GPUs has shown p and the residual history bit-identical through it and through the torch.distributed hooks,
+        # gathers included, the hooks carry the set-up halos and the norm and the peer-to-peer pushes the cycle's halos.
+        self.native = False if native is None else bool(native)
         self.native_active = False
         self.native_error = None
         self._cache = {}

@@ -81,7 +81,9 @@ def main():
         # FC is order independent, and exact-order RB reproduces the reference's sequential sweep per rank (its result
         # depends on the decomposition, and the emulated ranks decompose the same way): every rank's block is bit-identical
         assert np.array_equal(mg.grid(1).p, o.field("p", 1, rank)), rank
-        assert np.all(np.abs(hist - ho) <= 1e-13 + 1e-10 * np.abs(ho)), (hist, ho)
+        # p is bit-identical, so only the order of the norm's reduction differs from the oracle's: 1e-12 relative (the looser
+        # 1e-10 of north_star is kept for the reference's RECORDED series below, which were printed by another build)
+        assert np.all(np.abs(hist - ho) <= 1e-12 * np.abs(ho)), (hist, ho)
     else:  # parallel red-black: same-colour k=1 diagonals read as before the pass
         assert np.all(np.abs(hist - ho) <= 5e-5 * np.abs(ho))
     if golden:  # the reference's own recorded history for this decomposition (BASELINE.md 3.1, 2x2 column)

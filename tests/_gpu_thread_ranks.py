@@ -74,6 +74,11 @@ def rank_main(rank, tw, cfg, o, ho, no, results):
         assert n2 == n and np.array_equal(hist2, hist) and np.array_equal(mg.grid(1).p, p_first), rank
         assert nhydro.counters()["p2p_exchanges"] == c["p2p_exchanges"]
         comm.set_p2p(True)
+        # the prolongation's first-colour shortcut on OPEN-sided levels (neighbours instead of mirrors): same bits without it
+        nhydro.set_option("c2f_skip", 0)
+        n3, hist3 = mg.solve_p(tol, maxit)
+        nhydro.set_option("c2f_skip", 1)
+        assert n3 == n and np.array_equal(hist3, hist) and np.array_equal(mg.grid(1).p, p_first), rank
         # mg_testhalo.f90:75-92 on the 8-neighbour topology: the halo planes hold the neighbours' rank numbers
         g1 = mg.grid(1)
         g1.set("p", np.full(g1._shape("p"), float(rank)))

@@ -4,7 +4,8 @@ the same inputs, and against the reference's own known answers (tests/golden).
 Tolerances.  Four-colour ('FC') smoothing, the residual, the transfers and the coefficient set-up keep the
 reference's operation order and are compiled without FMA contraction, so their fields are compared EXACTLY
 (bit for bit) with the oracle.  Norms are reduced in a different order on the GPU: 1e-13 relative.  Residual
-histories: |d| <= 1e-13 + 1e-10*ref in units of ||b|| (north_star: 1e-10 relative).  Red-black ('RB') is order
+histories against the ORACLE (same fields, other reduction order): 1e-12 relative; against the reference's RECORDED series
+(tests/golden: another build, its libm): |d| <= 1e-13 + 1e-10*ref in units of ||b|| (north_star: 1e-10 relative).  Red-black ('RB') is order
 dependent in the reference itself; the parallel sweep is checked at the tolerance at which the
 reference agrees with itself across decompositions (1e-5 relative) plus the iteration count."""
 import numpy as np
@@ -283,7 +284,7 @@ def test_solve_fc_matches_oracle_and_golden(mg, golden):
     o.compute_rhs()
     no, ho, _ = o.solve_p()
     assert n == no == g["nite"]
-    assert np.all(np.abs(hist - ho) <= 1e-13 + 1e-10 * np.abs(ho))
+    assert np.all(np.abs(hist - ho) <= 1e-12 * np.abs(ho))   # oracle: same fields, another reduction order
     for k, ref in g["res_at"].items():  # the reference's own numbers
         assert abs(hist[int(k)] - ref) <= 1e-13 + 1e-10 * ref, (k, hist[int(k)], ref)
     p, po = mg.grid(1).p, o.field("p")
@@ -418,6 +419,7 @@ def test_stretched_sigma_coordinates(mg):
     o.compute_rhs()
     n, hist = mg.solve_p(1e-9, 50)
     no, ho, _ = o.solve_p(1e-9, 50)
+    # here the coefficients themselves differ in the last bits (device cosh / exp): north_star's bound, not the reduction-order one
     assert n == no and np.all(np.abs(hist - ho) <= 1e-13 + 1e-10 * np.abs(ho))
 
 
@@ -470,6 +472,71 @@ def test_warm_start_and_tictoc(mg, tmp_path):
         assert re.fullmatch(r" {21}( +#+){%d}" % (nl + 1), shape(mine[k + 1])) and len(mine[k + 1]) == len(mine[k]), mine[k + 1]
         assert all(shape(mine[k])[c:c + 10] == tl[21:31] for c in range(21, len(mine[k]), 10)), mine[k]
     assert cl.startswith(" " * 21)
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 16), (96, 48, 16), (24, 40, 8), (256, 128, 32)])
+def test_c2f_skip_is_invisible(mg, dims):
+    """Inside a cycle the prolongation leaves the (i odd, j odd) columns alone when a four-colour relax follows, because that
+    relax's FIRST colour is exactly (i odd, j odd) (mg_relax.f90:212-216) and overwrites them without reading them.  A/B: every
+    level's p after a V-cycle and after two F-cycle iterations with the shortcut (default) and without it (option "c2f_skip" = 0,
+    the reference's full update) must be the same bits -- on square, ragged and odd-quotient level shapes (24x40 -> 12x20 -> 6x10)."""
+    nx, ny, nz = dims
+    out = []
+    for skip in (1, 0):
+        mg.nhydro.set_option("c2f_skip", skip)
+        try:
+            _setup(mg, nx, ny, nz)
+            mg.nhydro.compute_rhs(*_uvw(nx, ny, nz, seed=4))
+            mg.Vcycle(1)
+            pv = [mg.grid(l).p for l in range(1, mg.nlevs() + 1)]
+            n, hist = mg.solve_p(1e-30, 2)
+            out.append((pv, [mg.grid(l).p for l in range(1, mg.nlevs() + 1)], hist))
+        finally:
+            mg.nhydro.set_option("c2f_skip", 1)
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_fortran_harness_bmask(mg, tmp_path):
+    """bmask = .true. through the Fortran boundary: the driver masks the boundary ring of rmask as the reference's does
+    (fill_halo_2D_bmask(1,rmask) before nhydro_matrices, mg_testseamount.f90 / mg_mpi_exchange.f90:357-391; `bmask` read from the
+    namelist as `use mg_namelist` gives it) and passes it to nhydro_matrices and nhydro_solve: sum(p**2), sum(div**2) and the printed
+    history equal the oracle's masked solve (that oracle branch has no reference-recorded answers: DESIGN.md section 2)."""
+    import os, re, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fortran", "testseamount_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("flang not available when build() ran")
+    mg.nhydro_clean()
+    (tmp_path / "nh_namelist").write_text("&nhparam\n relax_method = 'FC',\n solver_prec = 1.d-9,\n bmask = .true.,\n/\n")
+    out = subprocess.run([exe, "32", "48", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "- bmask         : T" in out.stdout
+    from oracle.mgoracle import Oracle, seamount_geometry
+    nx, ny, nz = 32, 48, 8
+    o = Oracle(nx, ny, nz, 1, 1, relax_method="FC", solver_prec=1e-9, bmask=True)
+    for name, a in zip(("dx", "dy", "zeta", "h"), seamount_geometry(nx, ny, 1, 1, 0)):
+        o.field(name)[...] = a
+    m = np.ones((nx + 2, ny + 2)); m[0, :] = m[-1, :] = 0.0; m[:, 0] = m[:, -1] = 0.0
+    o.field("rmask")[...] = m
+    o.matrices(4e3, 0.0, 0.0)
+    o.field("u")[...] = 0.0; o.field("v")[...] = 0.0
+    w = o.field("w"); w[0] = 0.0; w[1:] = -1.0
+    n, h, _ = o.nhydro_solve()
+    its = re.findall(r"ite = *(\d+): res = *([0-9.E+-]+) / conv", out.stdout)
+    assert len(its) == n
+    for (k, r) in its:
+        assert abs(float(r) - h[int(k)]) <= 5.1e-3 * h[int(k)]
+    sp2 = float(re.search(r"sum_p2 = *([0-9.E+-]+)", out.stdout).group(1))
+    assert np.isclose(sp2, (o.field("p")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-13)
+    o.check_nondivergence()
+    sd2 = float(re.search(r"sum_div2 = *([0-9.E+-]+)", out.stdout).group(1))
+    assert np.isclose(sd2, (o.field("b")[1:-1, 1:-1, :] ** 2).sum(), rtol=1e-9)
+    # and the unmasked run of the same block gives other numbers: the mask did reach the coefficients
+    (tmp_path / "nh_namelist").write_text("&nhparam\n relax_method = 'FC',\n solver_prec = 1.d-9,\n/\n")
+    out2 = subprocess.run([exe, "32", "48", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out2.returncode == 0
+    assert float(re.search(r"sum_p2 = *([0-9.E+-]+)", out2.stdout).group(1)) != sp2
 
 
 def test_zr_zw_kernel_against_reference_compiled_module(mg):
