@@ -28,6 +28,7 @@ struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 
 extern "C" {
 int mgxk_relax_ks_pair(hipStream_t, const LevView *, int, int, int, Sides);
+int mgxk_relax_ks_persist(hipStream_t, const LevView *, int, int, Sides, unsigned int *, unsigned int, int *);
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
@@ -106,6 +107,7 @@ struct Level {
   unsigned long long p2p_seq = 0;  // exchanges done on this level through the peer-to-peer transport
   size_t p2p_goff[2];           // gathered levels: ngroup blocks of the peer-to-peer gather, by parity
   unsigned long long p2p_gseq = 0;
+  unsigned int *ksp_done = nullptr; unsigned int ksp_seq = 0;  // per-plane progress counters of the persistent mid-level relax (k_relax_ksp) and their common value
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
   double *f2d_store[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *tab_store[2] = {nullptr, nullptr};  // m4,d4,m7,d7,h2,hi2,ze2 and cffw,csw (LevView)
@@ -136,6 +138,7 @@ struct State {
   std::vector<double *> peer_slab; std::vector<unsigned long long *> peer_flags;
   unsigned int *p2p_counter = nullptr;
   int *p2p_err = nullptr;   // host-mapped
+  int *kerr = nullptr;      // host-mapped error word of the persistent relax kernel (a plane's neighbour never showed up)
   long long n_p2p = 0;
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
   // the mask handed to nhydro_solve / nhydro_check_nondivergence on THIS call (nhydro.f90:72,82,98): staging copy in the
@@ -151,6 +154,7 @@ struct State {
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
+  int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
   std::string err, transport_name;
@@ -458,6 +462,11 @@ int relax(int lev, int nsweeps) {
   const int exact = S.method == M_RB && S.real && S.rb_exact;
   if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact)) { S.n_launch++; return 0; }
   const bool closed = all_physical(ph);
+  // closed mid levels, four colours: the whole call in one persistent launch, one workgroup per plane (mgx_relax_ks.hip: k_relax_ksp)
+  if (S.method == M_FC && closed && S.use_ksp && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr)) {
+    L.ksp_seq += (unsigned int)nsweeps; S.n_launch++;
+    return 0;
+  }
   double *const p1a = L.v.p1;
   for (int it = 1; it <= nsweeps; it++) {
     if (exact) {
@@ -875,6 +884,15 @@ int sync_stream() {
   // a kernel launch this thread issued since the last check was refused (launch configuration, LDS or register demand on this
   // device / ROCm): the operator it belonged to did not run, so the fields are not what the caller thinks -- fail loudly
   { hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail("a kernel launch was rejected: %s", hipGetErrorString(le)); }
+  if (S.kerr && *S.kerr) {
+    // a workgroup of the persistent relax kernel waited 2 s for its neighbour plane: some of its workgroups were kept off the chip
+    // (the GPU is shared with kernels that do not finish).  The sweep is incomplete: counters back to zero, the separate launches from now on.
+    *S.kerr = 0;
+    for (auto &L : S.lev) { if (L.ksp_done) (void)hipMemsetAsync(L.ksp_done, 0, (size_t)(L.nx + 2) * sizeof(unsigned int), S.stream); L.ksp_seq = 0; }
+    S.use_ksp = 0;
+    return fail("the persistent relax kernel timed out waiting for a neighbouring plane (its workgroups were not all resident); "
+                "the fields of that level are incomplete -- it is now OFF (one launch per colour pair)");
+  }
   if (S.p2p_err && *S.p2p_err) {
     // a missed exchange leaves the per-level sequence numbers of the two neighbours apart for good: every later exchange would
     // time out as well (5 s each).  The pushes are switched off on this rank; the caller has to re-establish them collectively
@@ -1140,12 +1158,13 @@ void mgx_clean(void) {
   p2p_release();
   for (void *q : S.allocs) (void)hipFree(q);
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
+  if (S.kerr) (void)hipHostFree(S.kerr);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1194,6 +1213,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int s = 0; s < 8; s++) CHK(dmalloc(&L.v.cA[s], L.n3js));
     CHK(dmalloc(&L.v.bet, L.n3js)); CHK(dmalloc(&L.v.gam, L.n3js));
     CHK(dmalloc(&L.v.p1, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.p1b, (size_t)(L.nx + 2) * L.v.RS)); L.v.p1w = nullptr;
+    { double *q = nullptr; CHK(dmalloc(&q, (size_t)(L.nx + 2) / 2 + 1)); L.ksp_done = (unsigned int *)q; L.ksp_seq = 0; }  // zeroed by dmalloc
     CHK(dmalloc(&L.zy_store, L.n3js)); CHK(dmalloc(&L.zx_store, L.n3js));
     L.v.zy = L.v.zx = nullptr;
     for (int q = 0; q < 7; q++) CHK(dmalloc(&L.f2d_store[q], (size_t)(L.nx + 2) * L.v.RS));
@@ -1234,6 +1254,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_partial, max_part));
   CHK(dmalloc(&S.d_scalar, 8));
   HIPCHK(hipHostMalloc((void **)&S.h_scalar, 8 * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&S.kerr, 64, hipHostMallocMapped));
+  *S.kerr = 0;
   Level &L1 = S.lev[0];
   S.ref_scratch_n = (size_t)8 * L1.nz * (L1.ny + 2) * (L1.nx + 2);
   CHK(dmalloc(&S.ref_scratch, S.ref_scratch_n));
@@ -1255,6 +1277,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
+  if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
   if (getenv("MGX_TICTOC")) S.tictoc = 1;
   if (getenv("MGX_RB_EXACT")) S.rb_exact = atoi(getenv("MGX_RB_EXACT"));
@@ -1427,6 +1450,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "rb_exact")) S.rb_exact = value;
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
+  else if (streq(name, "ksp")) S.use_ksp = value;
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;
@@ -1454,6 +1478,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "rb_exact")) *value = S.rb_exact;
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
+  else if (streq(name, "ksp")) *value = S.use_ksp;
   else if (streq(name, "p2p")) *value = S.p2p_on ? 1 : 0;
   else return fail("unknown option '%s'", name);
   return 0;

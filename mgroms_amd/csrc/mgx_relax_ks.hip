@@ -277,6 +277,23 @@ __device__ __forceinline__ void ks_tridiag(const double *sh, const double *__res
 #pragma unroll
   for (int k = 1; k <= NZ; k++) out[(k - 1) * stride + lane] = x[k - 1];
 }
+// the same with a2(k), bet(k) taken from LDS as the recurrence goes (their addresses do not depend on it): only x(k) in registers
+template <int NZ>
+__device__ __forceinline__ void ks_tridiag_lds(const double *sh, const double *__restrict__ sa2, const double *__restrict__ sbt, const int lane,
+                                               double *out, const int stride) {  // out may be sh itself
+  double x[NZ];
+  double xv = sh[lane] * sbt[lane];
+  x[0] = xv;
+#pragma unroll
+  for (int k = 2; k <= NZ; k++) {
+    xv = (sh[(k - 1) * WAVE + lane] - sa2[(k - 1) * WAVE + lane] * xv) * sbt[(k - 1) * WAVE + lane];
+    x[k - 1] = xv;
+  }
+#pragma unroll
+  for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - (sa2[k * WAVE + lane] * sbt[(k - 1) * WAVE + lane]) * x[k];  // gam(k+1) = dd(k)*bet(k)
+#pragma unroll
+  for (int k = 1; k <= NZ; k++) out[(k - 1) * stride + lane] = x[k - 1];
+}
 // store rows ka .. ka+R-1 of a column and the physical-boundary mirrors (mg_mpi_exchange.f90:509-537,552-597)
 // WT: write-through stores (agent scope, `sc1`): the persistent kernel hands planes to other workgroups inside one launch
 template <bool WT> __device__ __forceinline__ void ks_st(double *q, const double v) {
@@ -443,7 +460,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
   const int cA = L.HO + lane, jmA = L.EO + lane, jpA = jmA + 1;
   const int cB = L.EO + lane + 1, jmB = L.HO + lane, jpB = jmB + 1;
   const bool mW = ph.W && i == 1, mE = ph.E && i == L.nx;
-  const double *pr = L.p;
   KsRows<R> A, B;
   if (live) {
     ks_load_coef<NZ, R, REAL>(A, L, o, cA, jmA, jpA, ka, w == 0);
@@ -452,6 +468,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
   if (threadIdx.x == 0 && threadIdx.y == 0) s_bail = 0;
   __syncthreads();
   for (int s = 0; s < nsweeps; s++) {
+    // the addresses of a phase do not change from sweep to sweep: left alone, the compiler keeps all ~60 of them in registers across
+    // the loop (and spills the coefficients instead); an opaque copy of the base pointer makes it rebuild them, a few scalar adds
+    LevView Lc = L;
+    { double *pl = L.p; asm volatile("" : "+s"(pl)); Lc.p = pl; }
+    const double *pr = Lc.p;
     if (!(odd && s == 0)) {  // the first phase of an odd plane reads what the previous launch left
       if (threadIdx.x == 0 && threadIdx.y == 0) {
         const unsigned int need = base + (unsigned int)s + (odd ? 0u : 1u);
@@ -480,8 +501,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
         d1 = ks_ld<WT>(pr + om + jpA); d2 = ks_ld<WT>(pr + op + jmA); d3 = ks_ld<WT>(pr + om + jmA); d4 = ks_ld<WT>(pr + op + jpA);
         bd1 = ks_ld<WT>(pr + om + jpB); bd2 = ks_ld<WT>(pr + op + jmB); bd3 = ks_ld<WT>(pr + om + jmB); bd4 = ks_ld<WT>(pr + op + jpB);
       }
-      ks_load_p<NZ, R, WT>(A, L, o, cA, ka);
-      ks_load_p<NZ, R, WT>(B, L, o, cB, ka);
+      ks_load_p<NZ, R, WT>(A, Lc, o, cA, ka);
+      ks_load_p<NZ, R, WT>(B, Lc, o, cB, ka);
     }
     if (lane == 0) {
 #pragma unroll
@@ -489,10 +510,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
     }
     if (live) ks_rhs<NZ, R, REAL>(A, pjm, pjp, d1, d2, d3, d4, ka, lane, sh, sa2, sbt);
     __syncthreads();
-    if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, xa, XS);
+    if (w == 0 && live) ks_tridiag_lds<NZ>(sh, sa2, sbt, lane, xa, XS);
     __syncthreads();
     if (live) {
-      ks_store<R, WT>(L, o, cA, i, 2 * lane + 1, ka, lane, xa, XS, ph);
+      ks_store<R, WT>(Lc, o, cA, i, 2 * lane + 1, ka, lane, xa, XS, ph);
       double qjm[R + 2], qjp[R + 2];
 #pragma unroll
       for (int r = 0; r < R + 2; r++) {
@@ -506,9 +527,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
       ks_rhs<NZ, R, REAL>(B, qjm, qjp, bd1, bd2, bd3, bd4, ka, lane, sh, sa2, sbt);
     }
     __syncthreads();
-    if (w == 0 && live) ks_tridiag<NZ>(sh, sa2, sbt, lane, sh, WAVE);
+    if (w == 0 && live) ks_tridiag_lds<NZ>(sh, sa2, sbt, lane, sh, WAVE);
     __syncthreads();
-    if (live) ks_store<R, WT>(L, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
+    if (live) ks_store<R, WT>(Lc, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
     // publish: every storing wave drains its stores, the workgroup meets, one lane raises the plane's counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -583,8 +604,9 @@ int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int rea
   static const bool fence = getenv("MGX_KSP_FENCE") != nullptr;
   if (off || nsweeps < 1 || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || (L->nx & 1) || L->ny / 2 > WAVE) return 0;
   if ((L->nz != 16 && L->nz != 8) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
-  dim3 grd(L->nx), blk(WAVE, 8);
-#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, 8, RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err)
+  // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row
+  dim3 grd(L->nx), blk(WAVE, L->nz == 16 ? 4 : 8);
+#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 16 ? 4 : 8), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err)
   if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true); else KSP(16, true, false); } else { if (fence) KSP(16, false, true); else KSP(16, false, false); } }
   else { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
 #undef KSP

@@ -539,6 +539,42 @@ def test_fortran_harness_bmask(mg, tmp_path):
     assert float(re.search(r"sum_p2 = *([0-9.E+-]+)", out2.stdout).group(1)) != sp2
 
 
+@pytest.mark.parametrize("dims,par", [((128, 128, 16), {}), ((64, 128, 16), {}), ((96, 48, 16), {}), ((64, 64, 8), {}), ((128, 128, 16), {"cmatrix": "simple"}),
+                                      ((48, 96, 32), {"ns_pre": 1, "ns_post": 4})])
+def test_persistent_relax_equals_separate_launches(mg, dims, par):
+    """The persistent mid-level relax (k_relax_ksp: one workgroup per plane for a whole relax call, planes handed between workgroups
+    through per-plane progress counters) against one launch per colour pair (option "ksp" = 0): relax calls of 1..5 sweeps from a random
+    state on every level that qualifies (level 1 here; the cycles reach them as levels 3 and 4), then two F-cycle iterations -- the
+    same bits.  Run twice more with the counters already advanced (they are never reset between calls)."""
+    nx, ny, nz = dims
+    res = []
+    for ksp in (1, 0):
+        mg.nhydro.set_option("ksp", ksp)
+        try:
+            _setup(mg, nx, ny, nz, **par)
+            rng = np.random.default_rng(11)
+            got = []
+            for lev in range(1, mg.nlevs() + 1):
+                g = mg.grid(lev)
+                if g.nz not in (8, 16) or g.ny > 128 or g.nx > 128:
+                    continue
+                p0 = rng.standard_normal(g._shape("p")); b0 = rng.standard_normal(g._shape("b"))
+                g.set("b", b0)
+                for ns in (1, 2, 5, 3):
+                    g.set("p", p0); mg.fill_halo(lev, "p")
+                    mg.relax(lev, ns)
+                    got.append(g.get("p"))
+            mg.nhydro.compute_rhs(*_uvw(nx, ny, nz, seed=4))
+            n, hist = mg.solve_p(1e-30, 2)
+            got += [mg.grid(l).p for l in range(1, mg.nlevs() + 1)] + [hist]
+            res.append(got)
+        finally:
+            mg.nhydro.set_option("ksp", 1)
+    assert len(res[0]) == len(res[1]) > 3
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_zr_zw_kernel_against_reference_compiled_module(mg):
     """Row a13 on the device against the REAL reference: tests/golden/ref_zrzw.npz = zr, zw written by setup_zr_zw of
     mg_zr_zw.f90 compiled unmodified with flang (oracle/Makefile target `ref`).  theta = 0: no transcendental function, k_zr_zw
