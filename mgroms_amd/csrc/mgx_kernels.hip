@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256) void k_residual(LevView L, double *__restrict_
   }
 }
 
-// residual with matrix-free cross terms (see relax_col_mf): 18 streams per cell instead of 22
+// residual with matrix-free cross terms (see relax_col_mf): 17 streams per cell instead of 22.  The diagonal of the interior rows is
+// rebuilt from the fourteen couplings the row holds anyway (mg_define_matrix.f90:632-639, summed in the reference's order: the same bits
+// as the stored slot 1 -- as the smoother and the fused residual+restriction do); rows 1 and nz, whose formula differs, read the stored one.
+// The j-1 / j+1 neighbours of p and zy sit side by side in the other half-row: one 16-byte load each.  What only this lane reads (b, a2)
+// is streamed past the caches on a level that does not fit them.
 template <bool REAL>
 __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restrict__ partial, int want_norm, int gx, int gy, Sides ph, int stream) {
   // 1-D grid of gx*gy*2 blocks; XCD-aware map (see k_relax_nz): each XCD owns a contiguous range of plane groups,
@@ -136,29 +140,34 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
     double zy_m = 0, zy_0, zy_p, zx_m = 0, zx_0, zx_p, a2_0, a2_p;
 #define LOAD_WIN(q, PC, PJM, PIM, PJP, PIP, ZY, ZX, A2)                        \
   { const long long ro = (long long)((q)-1) * RS;                              \
-    PC = p[o + ro + c]; PJM = p[o + ro + jm]; PIM = p[om + ro + c]; PJP = p[o + ro + jp]; PIP = p[op + ro + c]; \
-    ZY = *(zy + o + ro + c); ZX = *(zx + o + ro + c); A2 = *(a2 + o + ro + c); }
+    PC = p[o + ro + c]; LD_PAIR(p + o + ro + jm, PJM, PJP) PIM = p[om + ro + c]; PIP = p[op + ro + c]; \
+    ZY = *(zy + o + ro + c); ZX = *(zx + o + ro + c); A2 = ld_rt(a2 + o + ro + c, stream); }
     LOAD_WIN(1, pc_0, pjm_0, pim_0, pjp_0, pip_0, zy_0, zx_0, a2_0)
     LOAD_WIN(2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
     for (int k = 1; k <= nz; k++) {
       const long long ro = (long long)(k - 1) * RS, ko = o + ro + c;
-      const double zyjm = zy[o + ro + jm], zyjp = zy[o + ro + jp], zxim = zx[om + ro + c], zxip = zx[op + ro + c];
-      const double a4jp = a4[o + ro + jp], a7ip = a7[op + ro + c];
+      double zyjm, zyjp;
+      LD_PAIR(zy + o + ro + jm, zyjm, zyjp)
+      const double zxim = zx[om + ro + c], zxip = zx[op + ro + c];
+      const double a4o = *(a4 + ko), a4jp = a4[o + ro + jp], a7o = *(a7 + ko), a7ip = a7[op + ro + c], bk = ld_rt(b + ko, stream);
       double rr;
       if (k == 1) {
-        rr = *(b + ko) - *(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - *(a4 + ko) * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - *(a7 + ko) * pim_0 - a7ip * pip_0
+        rr = bk - *(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - a4o * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - a7o * pim_0 - a7ip * pip_0
                    - (-qrt * (zxip + zx_p)) * pip_p;
         if (REAL)
           rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
       } else if (k < nz) {
-        rr = *(b + ko) - *(a1 + ko) * pc_0 - a2_0 * pc_m - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - (qrt * (zyjp + zy_m)) * pjp_m
-                   - *(a4 + ko) * pjm_0 - a4jp * pjp_0 - (-qrt * (zy_m + zyjm)) * pjm_m - (-qrt * (zyjp + zy_p)) * pjp_p
-                   - (qrt * (zx_p + zxim)) * pim_p - (qrt * (zxip + zx_m)) * pip_m - *(a7 + ko) * pim_0 - a7ip * pip_0
-                   - (-qrt * (zx_m + zxim)) * pim_m - (-qrt * (zxip + zx_p)) * pip_p;
+        const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p);
+        const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p);
+        const double dk = -a2_0 - a2_p - a4o - a4jp - a7o - a7ip - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;  // = cA(1,k,j,i), mg_define_matrix.f90:632-639
+        rr = bk - dk * pc_0 - a2_0 * pc_m - a2_p * pc_p - c3 * pjm_p - c3m * pjp_m
+                   - a4o * pjm_0 - a4jp * pjp_0 - c5 * pjm_m - c5m * pjp_p
+                   - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0
+                   - c8 * pim_m - c8m * pip_p;
       } else {
-        rr = *(b + ko) - *(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - *(a4 + ko) * pjm_0 - a4jp * pjp_0
-                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - *(a7 + ko) * pim_0 - a7ip * pip_0
+        rr = bk - *(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - a4o * pjm_0 - a4jp * pjp_0
+                   - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - a7o * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m;
       }
       st_rt(r + ko, rr, stream);

@@ -22,17 +22,28 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
   const int nx = G.nx, ny = G.ny, W = ny, PL = nx * ny;  // P[k][i-1][j-1], interior only
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
   const int lane = threadIdx.x;
-#define GI(k0, jj, ii) ((long long)(ii) * G.plane + (long long)(k0) * G.RS + jpos(G, jj))
-  {  // p -> LDS: at most 4 NZ cells per lane (<= 256 columns per wave), all loads in flight before the first LDS store
+  // 32-bit element offsets (these levels have a few thousand cells): base pointer in scalar registers + one 32-bit byte offset per load
+  // (the 64-bit index arithmetic of ~200 loads per lane and the divisions of a flat cell index were most of this kernel's fixed cost)
+  const int pl32 = (int)G.plane;
+#define GI(k0, jj, ii) ((ii) * pl32 + (k0) * G.RS + jpos(G, jj))
+#define LD32(arr, idx) (*(const double *)((const char *)(arr) + (unsigned)((idx) << 3)))
+  {  // p -> LDS: at most 4 cells per lane and level row (<= 256 columns per wave), all loads in flight before the first LDS store
     double tp[4 * NZ];
+    int cell[4];
 #pragma unroll
-    for (int u = 0; u < 4 * NZ; u++) {
-      const int t = lane + u * NT;
-      tp[u] = 0.0;
-      if (t < NZ * PL) { const int k0 = t / PL, r = t - k0 * PL, i = r / W, j = r - i * W; tp[u] = G.p[GI(k0, j + 1, i + 1)]; }
+    for (int v = 0; v < 4; v++) {
+      const int r = lane + v * NT;
+      const int i = r / W, j = r - i * W;
+      cell[v] = r < PL ? GI(0, j + 1, i + 1) : -1;
     }
 #pragma unroll
-    for (int u = 0; u < 4 * NZ; u++) { const int t = lane + u * NT; if (t < NZ * PL) P[t] = tp[u]; }
+    for (int k0 = 0; k0 < NZ; k0++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) tp[k0 * 4 + v] = cell[v] >= 0 ? LD32(G.p, cell[v] + k0 * G.RS) : 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < NZ; k0++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) if (cell[v] >= 0) P[k0 * PL + lane + v * NT] = tp[k0 * 4 + v];
   }
   const int nbj = ny >> 1;
   const bool mine = lane < (nx >> 1) * nbj;
@@ -46,16 +57,17 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int i = 2 * bi + 1 + (q >> 1), j = 2 * bj + 1 + (q & 1);
+      const int c0 = GI(0, j, i), cj0 = GI(0, j + 1, i), ci0 = c0 + pl32;
 #pragma unroll
       for (int k = 0; k < NZ; k++) {
-        const long long c = GI(k, j, i);
-        ob[q][k] = G.b[c]; a2[q][k] = G.cA[1][c]; a3[q][k] = G.cA[2][c]; a4[q][k] = G.cA[3][c]; a5[q][k] = G.cA[4][c];
-        a6[q][k] = G.cA[5][c]; a7[q][k] = G.cA[6][c]; a8[q][k] = G.cA[7][c]; bet[q][k] = G.bet[c];
-        if (q & 1) { const long long cj = GI(k, j + 1, i); xj[q >> 1][0][k] = G.cA[2][cj]; xj[q >> 1][1][k] = G.cA[3][cj]; xj[q >> 1][2][k] = G.cA[4][cj]; }
-        if (q >> 1) { const long long ci = GI(k, j, i + 1); xi[q & 1][0][k] = G.cA[5][ci]; xi[q & 1][1][k] = G.cA[6][ci]; xi[q & 1][2][k] = G.cA[7][ci]; }
+        const int c = c0 + k * G.RS;
+        ob[q][k] = LD32(G.b, c); a2[q][k] = LD32(G.cA[1], c); a3[q][k] = LD32(G.cA[2], c); a4[q][k] = LD32(G.cA[3], c); a5[q][k] = LD32(G.cA[4], c);
+        a6[q][k] = LD32(G.cA[5], c); a7[q][k] = LD32(G.cA[6], c); a8[q][k] = LD32(G.cA[7], c); bet[q][k] = LD32(G.bet, c);
+        if (q & 1) { const int cj = cj0 + k * G.RS; xj[q >> 1][0][k] = LD32(G.cA[2], cj); xj[q >> 1][1][k] = LD32(G.cA[3], cj); xj[q >> 1][2][k] = LD32(G.cA[4], cj); }
+        if (q >> 1) { const int ci = ci0 + k * G.RS; xi[q & 1][0][k] = LD32(G.cA[5], ci); xi[q & 1][1][k] = LD32(G.cA[6], ci); xi[q & 1][2][k] = LD32(G.cA[7], ci); }
       }
       e2[q] = e4[q] = 0.0;
-      if (REAL) { e2[q] = G.cA[4][GI(0, j - 1, i + 1)]; e4[q] = G.cA[7][GI(0, j + 1, i + 1)]; }
+      if (REAL) { e2[q] = LD32(G.cA[4], GI(0, j - 1, i + 1)); e4[q] = LD32(G.cA[7], GI(0, j + 1, i + 1)); }
     }
   }
   __syncthreads();
@@ -133,13 +145,17 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 #undef R6
 #undef R7
 #undef R8
-  // write back, halo included: every halo cell is the image of the interior cell its indices clamp to
+  // write back, halo included: every halo cell is the image of the interior cell its indices clamp to.  (ii, jj) of a lane's cells
+  // once (no division inside the row loop), 32-bit offsets as above
   const int WH = ny + 2, PLH = (nx + 2) * WH;
-  for (int t = lane; t < NZ * PLH; t += NT) {
-    const int k0 = t / PLH, r = t - k0 * PLH, ii = r / WH, jj = r - ii * WH;
+  for (int r = lane; r < PLH; r += NT) {
+    const int ii = r / WH, jj = r - ii * WH;
     const int ci = ii < 1 ? 1 : (ii > nx ? nx : ii), cj = jj < 1 ? 1 : (jj > ny ? ny : jj);
-    G.p[GI(k0, jj, ii)] = P[k0 * PL + (ci - 1) * W + (cj - 1)];
+    const int g0 = GI(0, jj, ii), l0 = (ci - 1) * W + (cj - 1);
+#pragma unroll
+    for (int k0 = 0; k0 < NZ; k0++) *(double *)((char *)G.p + (unsigned)((g0 + k0 * G.RS) << 3)) = P[k0 * PL + l0];
   }
+#undef LD32
 #undef GI
 }
 
