@@ -190,8 +190,12 @@ int mgx_counters(long long *out);
  * no host step, no callback.  Set-up is collective: every rank calls mgx_p2p_prepare (after mgx_init), the handle blobs
  * (mgx_p2p_handle_bytes() each) are all-gathered in rank order by the caller, every rank calls mgx_p2p_connect with
  * the concatenation.  mgx_set_option("p2p", 0|1) switches between this transport and the exchange callback (all
- * ranks together).  A neighbour that never shows up makes the next synchronising call fail (5 s device time-out) and switches the
- * pushes off on this rank: the sequence numbers of the two sides are then apart, so the ranks must agree and switch together. */
+ * ranks together).  A neighbour that never shows up ends the wait after 5 s (option "p2p_timeout_ms" / MGX_P2P_TIMEOUT_MS); the rank
+ * that waited does NOT fall back alone: it keeps exchanging and the ranks agree at the next global_sum (every solve_p iteration, every
+ * mgx_residual norm), whose all-reduce carries a second value "a wait of mine timed out": if any rank says so, EVERY rank switches
+ * to the hooks, rewinds its sequence numbers and returns the same error (the solve in progress is void; repeat it).  Test hook:
+ * option "p2p_test_drop" = n makes the n-th halo exchange of this rank keep its flags down; "p2p_failed" (mgx_get_option) reads the
+ * local marker. */
 int mgx_p2p_handle_bytes(void);
 int mgx_p2p_prepare(void *handles_out);
 int mgx_p2p_connect(const void *all_handles, int nranks);

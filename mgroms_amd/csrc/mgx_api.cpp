@@ -45,7 +45,9 @@ void mgxk_divc_selftest(hipStream_t, const double *, const double *, int, unsign
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
 void mgxk_halo_p2p(hipStream_t, const LevView *, double *, double *const *, double *const *, unsigned long long *const *,
-                   unsigned long long *const *, const int *, unsigned long long, unsigned int *, int *, const int *);
+                   unsigned long long *const *, const int *, unsigned long long, unsigned int *, int *, const int *, int);
+int mgxk_set_p2p_timeout(double);
+void mgxk_err_to_double(hipStream_t, const int *, int, double *);
 void mgxk_halo_pack_all(hipStream_t, const LevView *, double *, double *const *, const int *, int);
 void mgxk_convert(hipStream_t, const LevView *, double *, double *, int, int, int);
 void mgxk_convert8(hipStream_t, const LevView *, const double *);
@@ -140,6 +142,8 @@ struct State {
   int *p2p_err = nullptr;   // host-mapped
   int *kerr = nullptr;      // host-mapped error word of the persistent relax kernel (a plane's neighbour never showed up)
   long long n_p2p = 0;
+  int p2p_failed = 0;       // a wait of this rank timed out since the ranks last agreed (global_sum): reported collectively there
+  int p2p_test_drop = 0;    // test hook (option "p2p_test_drop" = n): the n-th halo exchange from now does not raise its flags
   double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
   // the mask handed to nhydro_solve / nhydro_check_nondivergence on THIS call (nhydro.f90:72,82,98): staging copy in the
   // caller's layout and the i-fastest copy the model-space kernels read; call_mask = a mask came with the current call
@@ -311,7 +315,9 @@ int fill_halo_js(Level &L, double *a, bool phys_done = false, bool xonly = false
       lbuf[d] = S.p2p_slab + L.p2p_off[d][par];
       lflag[d] = S.p2p_flags + (li * 8 + d) * 2 + par;
     }
-    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, lbuf, rflag, lflag, present, seq, S.p2p_counter, S.p2p_err, m);  // push, wait, unpack, mixed corners
+    int drop = 0;
+    if (S.p2p_test_drop > 0 && --S.p2p_test_drop == 0) drop = 1;
+    mgxk_halo_p2p(S.stream, &L.v, a, rbuf, lbuf, rflag, lflag, present, seq, S.p2p_counter, S.p2p_err, m, drop);  // push, wait, unpack, mixed corners
     S.n_launch++; S.n_p2p++;
   } else if (n) {
     mgxk_halo_pack_all(S.stream, &L.v, a, S.xbuf, present, 0); S.n_launch++;       // all edges + corners, one launch
@@ -392,14 +398,29 @@ int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c, bool xonly = fals
 }
 
 // global_sum (mg_mpi_exchange.f90:1555-1571) of the value in d_scalar[0]; returns it on the host
+// The all-reduce doubles as the point where the ranks AGREE on the health of the peer-to-peer transport: a second value carries
+// "a wait of mine timed out" (the device-side error word, read in stream order, or a time-out an earlier sync saw).  If any rank
+// says so, every rank switches the pushes off, rewinds its sequence numbers and flags, and returns the same error: nobody is
+// left pushing to, or waiting for, a rank that fell back alone.
 int global_sum(const Level &L, double *out) {
+  const bool agree = S.nranks > 1 && S.p2p_ready;
   if (S.nranks > 1) {
     if (!S.ar) return fail("an all-reduce is needed (npx*npy > 1) but mgx_set_comm was not called");
     S.n_allred++;
-    if (S.ar(S.ctx, S.d_scalar, 1)) return fail("allreduce callback failed");
+    if (agree) { mgxk_err_to_double(S.stream, S.p2p_err, S.p2p_failed, S.d_scalar + 1); S.n_launch++; }
+    if (S.ar(S.ctx, S.d_scalar, agree ? 2 : 1)) return fail("allreduce callback failed");
   }
-  HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, sizeof(double), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   CHK(sync_stream());
+  if (agree && S.h_scalar[1] > 0.0) {
+    S.p2p_on = false; S.p2p_failed = 0;
+    if (S.p2p_err) *S.p2p_err = 0;
+    for (auto &Lv : S.lev) { Lv.p2p_seq = 0; Lv.p2p_gseq = 0; }
+    HIPCHK(hipMemsetAsync(S.p2p_flags, 0, 4096 * sizeof(unsigned long long), S.stream));
+    HIPCHK(hipStreamSynchronize(S.stream));
+    return fail("the peer-to-peer halo transport timed out on %d rank(s): ALL ranks have switched to the hooks together (sequence numbers "
+                "rewound); the halos of the affected exchanges were stale, so the current solve is void -- repeat it", (int)S.h_scalar[1]);
+  }
   *out = S.h_scalar[0] * (L.npx * L.npy) / (S.lev[0].npx * S.lev[0].npy);
   return 0;
 }
@@ -894,13 +915,13 @@ int sync_stream() {
                 "the fields of that level are incomplete -- it is now OFF (one launch per colour pair)");
   }
   if (S.p2p_err && *S.p2p_err) {
-    // a missed exchange leaves the per-level sequence numbers of the two neighbours apart for good: every later exchange would
-    // time out as well (5 s each).  The pushes are switched off on this rank; the caller has to re-establish them collectively
-    // (mgx_set_option("p2p", 1) on every rank after agreeing, or a new mgx_init + mgx_p2p_connect).
+    // A wait on a neighbour's flag timed out (the edge it was waiting for stayed stale).  This rank must NOT fall back alone -- its
+    // neighbours would go on pushing to flags nobody reads and waiting for pushes that never come: it keeps exchanging (the
+    // sequence numbers stay in step, flags are compared with >=) and remembers; the ranks agree at the next global_sum (every
+    // solve_p iteration, every norm), where all of them switch to the hooks together and report the error.
     *S.p2p_err = 0;
-    S.p2p_on = false;
-    return fail("peer-to-peer halo exchange timed out waiting for a neighbour; the peer-to-peer transport is now OFF on this rank "
-                "(halos fall back to the hooks): all ranks must switch together before going on");
+    S.p2p_failed = 1;
+    if (S.verbose) fprintf(stderr, "mgx warning: rank %d: a peer-to-peer halo wait timed out; reported collectively at the next norm\n", S.rank);
   }
   return 0;
 }
@@ -1278,6 +1299,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
+  if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
   if (getenv("MGX_TICTOC")) S.tictoc = 1;
   if (getenv("MGX_RB_EXACT")) S.rb_exact = atoi(getenv("MGX_RB_EXACT"));
@@ -1451,6 +1473,8 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "ksp")) S.use_ksp = value;
+  else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
+  else if (streq(name, "p2p_timeout_ms")) { if (mgxk_set_p2p_timeout((double)value)) return fail("p2p_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;
@@ -1479,6 +1503,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "ksp")) *value = S.use_ksp;
+  else if (streq(name, "p2p_failed")) *value = S.p2p_failed;
   else if (streq(name, "p2p")) *value = S.p2p_on ? 1 : 0;
   else return fail("unknown option '%s'", name);
   return 0;

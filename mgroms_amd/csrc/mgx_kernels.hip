@@ -536,7 +536,10 @@ __global__ void k_halo_pack_all(LevView L, double *__restrict__ a, HaloBufs hb, 
 // neighbour's flag.  Unpack: a block spins (bounded) on the LOCAL flag of its direction, then copies the received edge
 // into the halo.  Receive buffers alternate by the parity of the per-level sequence number:
 // a rank cannot push exchange n+2 before it has unpacked n+1, which its neighbour pushed after unpacking n.
+// bound of every wait on a peer's flag, in ticks of the 100 MHz constant clock (5 s; MGX_P2P_TIMEOUT_MS / mgxk_set_p2p_timeout shorten it for tests)
+__device__ long long g_p2p_timeout_ticks = 500000000LL;
 struct HaloP2P {
+  int drop;                     // test hook: this launch does not raise the neighbours' flags (a rank that went silent)
   unsigned long long *flag[8];  // push: the neighbour's flag to raise; unpack: the local flag to wait on
   unsigned long long seq;
   unsigned int *counter;        // blocks-done counter of the push launch (device memory, left at 0)
@@ -578,13 +581,13 @@ __global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__rest
       __hip_atomic_store(pp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       for (int d = 0; d < 8; d++)
-        if (hx.present[d]) __hip_atomic_store(hx.rflag[d], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (hx.present[d] && !pp.drop) __hip_atomic_store(hx.rflag[d], pp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     ok = 0;
-    const long long t0 = wall_clock64();
+    const long long t0 = wall_clock64(), tmax = g_p2p_timeout_ticks;
     while (true) {
       if (__hip_atomic_load(hx.lflag[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= pp.seq) { ok = 1; break; }
-      if (wall_clock64() - t0 > 500000000LL) break;  // 5 s of the 100 MHz constant clock: the neighbour is gone
+      if (wall_clock64() - t0 > tmax) break;  // 5 s of the 100 MHz constant clock: the neighbour is gone
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -693,10 +696,10 @@ __global__ void k_gather_place_wait(LevView C, double *__restrict__ dstjs, const
     __shared__ int ok;
     if (threadIdx.x == 0) {
       ok = 0;
-      const long long t0 = wall_clock64();
+      const long long t0 = wall_clock64(), tmax = g_p2p_timeout_ticks;
       while (true) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) { ok = 1; break; }
-        if (wall_clock64() - t0 > 500000000LL) break;
+        if (wall_clock64() - t0 > tmax) break;
         __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -807,8 +810,9 @@ void mgxk_halo_pack_all(hipStream_t st, const LevView *L, double *a, double *con
   hipLaunchKernelGGL(k_halo_pack_all, dim3((n + 63) / 64, L->nz, 8), dim3(64), 0, st, *L, a, hb, unpack);
 }
 void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *rbuf, double *const *lbuf, unsigned long long *const *rflag,
-                   unsigned long long *const *lflag, const int *present, unsigned long long seq, unsigned int *counter, int *err, const int *mixed) {
+                   unsigned long long *const *lflag, const int *present, unsigned long long seq, unsigned int *counter, int *err, const int *mixed, int drop) {
   HaloXchg hx; HaloP2P pp;
+  pp.drop = drop;
   // Every block both pushes and waits, so all of them must be resident together, and a waiting wave, however light, keeps
   // a 512-VGPR smoother wave off its SIMD: harmless when the GPU belongs to one rank (the smoother is behind us in the
   // stream), fatal when several ranks share one GPU as in the tests (the neighbour's smoother would never start).  So the
@@ -835,6 +839,15 @@ void mgxk_halo_p2p(hipStream_t st, const LevView *L, double *a, double *const *r
   if (nb == 0) return;
   hipLaunchKernelGGL(k_halo_exchange, dim3(nb), dim3(256), 0, st, *L, a, hx, pp);
 }
+// the bound of every p2p flag wait, in milliseconds (device global of this library; all instances of the process)
+int mgxk_set_p2p_timeout(double ms) {
+  const long long ticks = (long long)(ms * 1e5);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_p2p_timeout_ticks), &ticks, sizeof ticks) == hipSuccess ? 0 : 1;
+}
+// out[0] = 1.0 when the host-mapped error word is set or `extra` is non-zero, else 0.0 -- in stream order, so that a time-out of a kernel
+// still in flight reaches the all-reduce that follows (collective agreement on the health of the peer-to-peer transport)
+__global__ void k_err_to_double(const int *err, int extra, double *out) { out[0] = (err && *err != 0) || extra ? 1.0 : 0.0; }
+void mgxk_err_to_double(hipStream_t st, const int *err, int extra, double *out) { hipLaunchKernelGGL(k_err_to_double, dim3(1), dim3(1), 0, st, err, extra, out); }
 void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int nslot, int slot, int dir) {
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
   hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *L, js, ref, nslot, slot, dir);

@@ -4,7 +4,7 @@ is how BASELINE config 5's 4x2 process grid (8 ranks, a 2x2 gather followed by a
 the one GPU of a test box, which admits at most 6 processes on its card.  Every rank's block is compared bit for bit with the
 oracle's emulated MPI ranks, through the peer-to-peer pushes and again through the mgx_set_comm hooks.
 
-usage: _gpu_thread_ranks.py npx npy nx ny nz nsmall"""
+usage: _gpu_thread_ranks.py npx npy nx ny nz nsmall [drop]     (drop: one rank goes silent for one exchange first, see rank_main)"""
 import os
 import sys
 import threading
@@ -23,7 +23,7 @@ def rank_main(rank, tw, cfg, o, ho, no, results):
     from mgroms_amd._lib import check, lib
     from mgroms_amd.parallel import ThreadComm
     from oracle.mgoracle import seamount_geometry
-    npx, npy, nx, ny, nz, nsmall, tol, maxit, nsc = cfg
+    npx, npy, nx, ny, nz, nsmall, tol, maxit, nsc, drop = cfg
 
     def stage(what):
         print(f"[rank {rank}] {what}", file=sys.stderr, flush=True)
@@ -45,6 +45,27 @@ def rank_main(rank, tw, cfg, o, ho, no, results):
         u = np.zeros((nz, ny + 2, nx + 1)); v = np.zeros((nz, ny + 1, nx + 2)); w = -np.ones((nz + 1, ny + 2, nx + 2)); w[0] = 0
         nhydro.compute_rhs(u, v, w)
         stage("matrices + rhs done")
+        if drop:
+            # A rank goes silent for one exchange (test hook: its flags stay down): its neighbours' waits time out (200 ms here).  Nobody
+            # may fall back alone -- the ranks agree at the next norm and ALL of them get the same error and the same transport.
+            from mgroms_amd._lib import MgxError
+            nhydro.set_option("p2p_timeout_ms", 200)
+            tw.barrier.wait(60)
+            if rank == tw.world - 1:
+                nhydro.set_option("p2p_test_drop", 7)
+            try:
+                mg.solve_p(tol, maxit)
+                raise AssertionError("the solve with a silent rank did not fail")
+            except MgxError as e:
+                assert "ALL ranks have switched to the hooks together" in str(e), str(e)
+            stage("collective fallback seen")
+            assert "peer-to-peer" not in comm.transport(), comm.transport()
+            before = nhydro.counters()["p2p_exchanges"]
+            n, hist = mg.solve_p(tol, maxit)          # the repeat, through the hooks on every rank
+            assert nhydro.counters()["p2p_exchanges"] == before
+            assert n == no and np.array_equal(mg.grid(1).p, o.field("p", 1, rank)), rank
+            comm.set_p2p(True)                         # and the pushes can be switched on again, all ranks together
+            nhydro.set_option("p2p_timeout_ms", 5000)
         n, hist = mg.solve_p(tol, maxit)
         stage("solve done")
         assert mg.nlevs() == o.nlevs
@@ -124,7 +145,7 @@ def main():
     no, ho, _ = o.solve_p(tol, maxit)
     tw = ThreadWorld(world)
     results = [None] * world
-    cfg = (npx, npy, nx, ny, nz, nsmall, tol, maxit, nsc)
+    cfg = (npx, npy, nx, ny, nz, nsmall, tol, maxit, nsc, len(sys.argv) > 7 and sys.argv[7] == "drop")
     th = [threading.Thread(target=rank_main, args=(r, tw, cfg, o, ho, no, results), daemon=True) for r in range(world)]
     for t in th:
         t.start()

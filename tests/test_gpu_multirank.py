@@ -79,6 +79,19 @@ def test_config5_4x2_ranks_in_one_process(npx, npy, nx, ny, nz, nsmall):
         assert "gathered_levels=[2, 3]" in out.stdout, out.stdout
 
 
+def test_p2p_timeout_is_agreed_collectively():
+    """A rank whose pushes stop for one exchange (test hook "p2p_test_drop"): its neighbours' waits time out, and instead of falling
+    back alone (which would leave the others pushing to flags nobody reads) every rank learns it at the next global_sum -- the
+    all-reduce carries the health flag -- gets the same error, switches to the hooks, and the repeated solve is bit-identical to
+    the oracle; then the pushes come back on collectively (mg_mpi_exchange.f90:504-718 has no counterpart: MPI_Waitall blocks)."""
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_gpu_thread_ranks.py"), "2", "2", "16", "16", "8", "8", "drop"],
+                         capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-3000:]
+    for r in range(4):
+        assert f"rank {r} ok" in out.stdout
+    assert out.stderr.count("collective fallback seen") == 4
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` from a bare shell (no launcher): bench.py starts its own ranks before touching the GPU.
     Rehearsed here with both ranks on the one GPU of the box (--backend gloo: host-staged callbacks + hipIpc pushes)."""
