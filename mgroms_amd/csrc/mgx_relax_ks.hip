@@ -16,6 +16,12 @@
 // H > 1 (nz = 64, the second level of an nz = 128 hierarchy): a wave's NZ/NW rows are built in H runs of R rows one after the other (the register
 // arrays of a run are those of the nz = 32 kernel), the recurrence wave keeps only x(k) in registers and takes a2(k), bet(k) from LDS as it
 // goes, and the three parked arrays are dynamic LDS (96 KB).
+#ifdef MGX_KS_STAMP  // diagnostic build only (scripts/probe/ks_timeline.py): in-kernel time stamps of the phases of a pass
+__device__ long long g_ks_stamp[1024 * 8];
+#define KS_STAMP(q) { if (threadIdx.x == 0 && (w == 0 || w == NW - 1) && blockIdx.x < 512) g_ks_stamp[(blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (q)] = (q) == 7 ? (long long)wall_clock64() : (long long)__builtin_amdgcn_s_memtime(); }
+#else
+#define KS_STAMP(q)
+#endif
 template <int NZ, int NW, bool REAL, bool SNAP, int H = 1>
 __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph, int gx) {
   constexpr int R = NZ / NW / H;  // rows per wave and run
@@ -30,6 +36,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
     bx = local - (local / gx) * gx;
   } else { ipl = blockIdx.x / gx; bx = blockIdx.x - ipl * gx; }
   const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row ranges in scalar registers
+  KS_STAMP(0) KS_STAMP(7)
   const int jh = bx * WAVE + lane;
   const bool live = jh < (L.ny >> 1);  // ragged last chunk: dead lanes still join the barriers
   const int i = i0 + istep * ipl;
@@ -80,6 +87,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
         e1 = a5[o + c]; e2 = a5[op + jm]; e3 = a8[o + c]; e4 = a8[op + jp];
       }
     }
+#ifdef MGX_KS_STAMP
+    KS_STAMP(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KS_STAMP(2)
+#endif
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const int k = ka + r;
@@ -110,6 +122,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
   }
   }
   __syncthreads();
+  KS_STAMP(3)
   // ---- phase 2 (wave 0): tridiag (mg_relax.f90:322-332) on the parked right-hand sides
   if (H > 1) {
     if (w == 0 && live) {  // x(k) in registers only; a2(k), bet(k) stream from LDS (their addresses do not depend on the recurrence)
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
     }
   }
   __syncthreads();
+  KS_STAMP(4)
   // ---- phase 3: every wave stores its rows (+ the physical-boundary mirrors, mg_mpi_exchange.f90:509-537,552-597)
   if (!live) return;
   const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
@@ -178,7 +192,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
   }
+#ifdef MGX_KS_STAMP
+  KS_STAMP(5)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  KS_STAMP(6)
+#endif
 }
+#ifdef MGX_KS_STAMP
+extern "C" int mgxk_ks_stamps(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ks_stamp), sizeof(long long) * 1024 * 8) == hipSuccess ? 0 : 1; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Two colours of the four-colour sweep in one launch.  Colours 1 and 2 (mg_relax.f90:214-217: i odd with j odd, then i odd with

@@ -5,7 +5,7 @@
 # PMC counters are collected in passes of their own (FETCH_SIZE and WRITE_SIZE do not fit one pass), never together with
 # the runtime trace domains.
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -18,8 +18,13 @@ stats() {  # $1 = tag, rest = program
 stats bench python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 || exit 1
 # 2. V-cycles only (no set-up noise in the averages)
 stats vcycle python3 $ROOT/scripts/profile_vcycle.py 512 512 64 FC 20 || exit 1
-# 3. BASELINE config 5's level-1 shape (nz = 128)
+# 3. BASELINE config 5's level-1 shape (nz = 128): sweeps, and V-cycles of the 512x512x128 and of the real 512x1024x128 block
 stats nz128 python3 $ROOT/scripts/sweep_time.py 512 512 128 FC 10 || exit 1
+stats nz128_vcycle python3 $ROOT/scripts/profile_vcycle.py 512 512 128 FC 10 || exit 1
+stats config5_512x1024x128 python3 $ROOT/scripts/profile_vcycle.py 512 1024 128 FC 5 || exit 1
+# 3b. solve_p iterations (F-cycle + residual): per-kernel time per iteration
+timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $OUT/${R}_solve -- python3 $ROOT/scripts/profile_solve.py 512 512 64 FC 10 > $OUT/${R}_solve.log 2>&1 || exit 1
+python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_solve/*/*_kernel_trace.csv | head -1) 10 > $ROOT/profiles/${R}_solve_breakdown.txt || exit 1
 # 4. HBM traffic of the dominant kernels, same bench command, two PMC passes
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_fetch -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_write -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_write.log 2>&1 || exit 1
