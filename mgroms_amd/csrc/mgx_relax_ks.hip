@@ -456,11 +456,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks2(LevView L, int i0, int
 //     even plane i, sweep s : waits until planes i-1, i+1 have finished s+1 phases, runs colours 3+4, publishes s+1
 // A plane's only inter-workgroup dependencies are its two neighbour planes (p at i-1 / i+1 incl. the k=1 diagonals); the waits
 // above order every read after the write it needs and every write after the last read of the value it replaces.
-// Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every load and store of p is an
-// agent-scope (sc1) access -- write-through stores, L1-bypassing loads --, each storing wave drains its stores (s_waitcnt vmcnt(0)),
-// the workgroup meets at a barrier, one lane stores the counter (sc1); the consumer polls it with one lane (sc1 loads, s_sleep
-// between polls) and releases its workgroup through a barrier.  FENCE = true swaps this for plain accesses between an agent-scope
-// release and acquire fence (the architecturally guaranteed form; A/B).  All nx workgroups must be resident together (<= 128 of
+// Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  FENCE = true (default): plain
+// stores, each storing wave drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane issues an agent-scope release
+// fence and stores the counter; the consumer polls it with one lane (relaxed agent-scope loads, s_sleep between polls), issues an
+// agent-scope acquire fence and releases its workgroup through a barrier, after which plain loads see the neighbour planes.
+// FENCE = false (MGX_KSP_SC1=1, A/B): no fences, every load and store of p is an agent-scope (sc1) access instead -- write-through
+// stores, L1-bypassing loads -- which the guide measured as sufficient on gfx950 but does not call an architectural guarantee.  All nx workgroups must be resident together (<= 128 of
 // them, one per CU: 512 threads at up to 256 registers); the poll is bounded (2 s of the constant clock -> error word, reported by
 // the next synchronising call) so that a co-tenant that keeps a workgroup off the chip cannot hang the stream.
 // Same expressions in the same order as k_relax_ks2: bit-identical.
@@ -623,7 +624,9 @@ int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, in
 // done: nx + 2 progress counters of the level (zero at init), base: their common value now; the caller adds nsweeps afterwards.
 int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int real, Sides ph, unsigned int *done, unsigned int base, int *err) {
   static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr || getenv("MGX_NO_KSP") != nullptr;
-  static const bool fence = getenv("MGX_KSP_FENCE") != nullptr;
+  // default: plain accesses between agent-scope release / acquire fences (the architecturally guaranteed hand-off); MGX_KSP_SC1=1: the
+  // fence-free form with sc1 stores and loads (measured on gfx950 only) -- the two time the same (F-cycle 283-285 vs 285 it/s)
+  static const bool fence = getenv("MGX_KSP_SC1") == nullptr;
   if (off || nsweeps < 1 || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || (L->nx & 1) || L->ny / 2 > WAVE) return 0;
   if ((L->nz != 16 && L->nz != 8) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
   // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row
