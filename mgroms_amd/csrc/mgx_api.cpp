@@ -28,7 +28,8 @@ struct ModelView { double *u, *v, *w, *rmask; int bmask; };
 
 extern "C" {
 int mgxk_relax_ks_pair(hipStream_t, const LevView *, int, int, int, Sides);
-int mgxk_relax_ks_persist(hipStream_t, const LevView *, int, int, Sides, unsigned int *, unsigned int, int *);
+int mgxk_relax_ks_persist(hipStream_t, const LevView *, int, int, Sides, unsigned int *, unsigned int, int *, int);
+int mgxk_set_ksp_timeout(double);
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
@@ -158,6 +159,7 @@ struct State {
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
+  int ksp_test_stall = 0;  // test hook (option "ksp_test_stall" = i): in the next persistent relax the workgroup of plane i returns at once
   int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -484,7 +486,8 @@ int relax(int lev, int nsweeps) {
   if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact)) { S.n_launch++; return 0; }
   const bool closed = all_physical(ph);
   // closed mid levels, four colours: the whole call in one persistent launch, one workgroup per plane (mgx_relax_ks.hip: k_relax_ksp)
-  if (S.method == M_FC && closed && S.use_ksp && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr)) {
+  if (S.method == M_FC && closed && S.use_ksp && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr, S.ksp_test_stall)) {
+    S.ksp_test_stall = 0;
     L.ksp_seq += (unsigned int)nsweeps; S.n_launch++;
     return 0;
   }
@@ -1473,6 +1476,8 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "ksp")) S.use_ksp = value;
+  else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
+  else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
   else if (streq(name, "p2p_timeout_ms")) { if (mgxk_set_p2p_timeout((double)value)) return fail("p2p_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges

@@ -466,8 +466,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks2(LevView L, int i0, int
 // the next synchronising call) so that a co-tenant that keeps a workgroup off the chip cannot hang the stream.
 // Same expressions in the same order as k_relax_ks2: bit-identical.
 // ------------------------------------------------------------------------------------------------
+// bound of a plane's wait for its neighbours, ticks of the 100 MHz constant clock (2 s; mgxk_set_ksp_timeout shortens it for the test)
+__device__ long long g_ksp_timeout_ticks = 200000000LL;
 template <int NZ, int NW, bool REAL, bool FENCE>
-__global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps, Sides ph, unsigned int *done, unsigned int base, int *err) {
+__global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps, Sides ph, unsigned int *done, unsigned int base, int *err, int stall) {
   constexpr int R = NZ / NW;     // rows per wave
   constexpr int XS = WAVE + 1;
   constexpr bool WT = !FENCE;
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
   __shared__ int s_bail;
   int i = blockIdx.x + 1;
   if ((L.nx & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; i = xcd * (L.nx >> 3) + local + 1; }  // neighbour planes share an XCD (speed only)
+  if (i == stall) return;  // test hook: this plane's workgroup never shows up (as if a co-tenant kept it off the chip)
   const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int nh = L.ny >> 1;
   const bool live = lane < nh, odd = (i & 1) != 0;
@@ -499,13 +502,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
     if (!(odd && s == 0)) {  // the first phase of an odd plane reads what the previous launch left
       if (threadIdx.x == 0 && threadIdx.y == 0) {
         const unsigned int need = base + (unsigned int)s + (odd ? 0u : 1u);
-        const long long t0 = wall_clock64();
+        const long long t0 = wall_clock64(), tmax = g_ksp_timeout_ticks;
         for (;;) {
           bool ok = true;
           if (i > 1) ok = ok && (int)(__hip_atomic_load(done + i - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
           if (i < L.nx) ok = ok && (int)(__hip_atomic_load(done + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
           if (ok) break;
-          if (wall_clock64() - t0 > 200000000LL) { *err = 1; s_bail = 1; break; }  // 2 s at 100 MHz
+          if (wall_clock64() - t0 > tmax) { *err = 1; s_bail = 1; break; }  // 2 s at 100 MHz
           __builtin_amdgcn_s_sleep(1);
         }
         if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -622,7 +625,12 @@ int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, in
 
 // all nsweeps four-colour sweeps of a closed mid level in one persistent launch (k_relax_ksp); returns 1 when launched.
 // done: nx + 2 progress counters of the level (zero at init), base: their common value now; the caller adds nsweeps afterwards.
-int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int real, Sides ph, unsigned int *done, unsigned int base, int *err) {
+int mgxk_set_ksp_timeout(double ms) {
+  const long long ticks = (long long)(ms * 1e5);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ksp_timeout_ticks), &ticks, sizeof ticks) == hipSuccess ? 0 : 1;
+}
+// stall: test hook, the plane whose workgroup returns at once (0 = none)
+int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int real, Sides ph, unsigned int *done, unsigned int base, int *err, int stall) {
   static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr || getenv("MGX_NO_KSP") != nullptr;
   // default: plain accesses between agent-scope release / acquire fences (the architecturally guaranteed hand-off); MGX_KSP_SC1=1: the
   // fence-free form with sc1 stores and loads (measured on gfx950 only) -- the two time the same (F-cycle 283-285 vs 285 it/s)
@@ -631,7 +639,7 @@ int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int rea
   if ((L->nz != 16 && L->nz != 8) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
   // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row
   dim3 grd(L->nx), blk(WAVE, L->nz == 16 ? 4 : 8);
-#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 16 ? 4 : 8), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err)
+#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 16 ? 4 : 8), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err, stall)
   if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true); else KSP(16, true, false); } else { if (fence) KSP(16, false, true); else KSP(16, false, false); } }
   else { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
 #undef KSP

@@ -57,6 +57,13 @@ def set_option(name, value):
     check(lib().mgx_set_option(name.encode(), int(value)))
 
 
+def get_option(name):
+    """read back an option or an integer / logical member of /nhparam/ (include/mgx.h: mgx_get_option)"""
+    v = C.c_int()
+    check(lib().mgx_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
 def print_tictoc(path="fort.10"):
     """print_tictoc (mg_tictoc.f90:114): per-level timer table of relax / residual / Fcycle / solve / compute_rhs."""
     check(lib().mgx_print_tictoc(path.encode()))

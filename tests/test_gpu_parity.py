@@ -575,6 +575,37 @@ def test_persistent_relax_equals_separate_launches(mg, dims, par):
         assert np.array_equal(a, b)
 
 
+def test_persistent_relax_timeout_falls_back(mg):
+    """The persistent relax needs all its workgroups resident together.  If one never shows up (test hook: the workgroup of plane 5
+    returns at once, as if a co-tenant of the GPU kept it off the chip) its neighbours' bounded polls expire (50 ms here, 2 s in
+    production), the next synchronising call fails loudly, the kernel is switched off for this instance, and the same relax call
+    through one launch per colour pair gives the oracle's bits."""
+    from mgroms_amd._lib import MgxError
+    nx, ny, nz = 64, 64, 8
+    o = _setup(mg, nx, ny, nz)
+    rng = np.random.default_rng(2)
+    g = mg.grid(1)
+    p0 = rng.standard_normal(g._shape("p")); b0 = rng.standard_normal(g._shape("b"))
+    g.set("b", b0); g.set("p", p0); mg.fill_halo(1, "p")
+    o.field("p")[...] = p0; o.field("b")[...] = b0; o.fill_halo(1, "p")
+    o.relax(1, 3)
+    mg.nhydro.set_option("ksp_timeout_ms", 50)
+    mg.nhydro.set_option("ksp_test_stall", 5)
+    try:
+        with pytest.raises(MgxError, match="persistent relax kernel timed out"):
+            mg.relax(1, 3)
+        assert mg.nhydro.get_option("ksp") == 0
+        g.set("p", p0); mg.fill_halo(1, "p")
+        mg.relax(1, 3)                       # separate launches now
+        assert np.array_equal(g.get("p"), o.field("p"))
+    finally:
+        mg.nhydro.set_option("ksp_timeout_ms", 2000)
+        mg.nhydro.set_option("ksp", 1)
+    g.set("p", p0); mg.fill_halo(1, "p")
+    mg.relax(1, 3)                           # and the persistent kernel again, counters rewound
+    assert np.array_equal(g.get("p"), o.field("p"))
+
+
 def test_zr_zw_kernel_against_reference_compiled_module(mg):
     """Row a13 on the device against the REAL reference: tests/golden/ref_zrzw.npz = zr, zw written by setup_zr_zw of
     mg_zr_zw.f90 compiled unmodified with flang (oracle/Makefile target `ref`).  theta = 0: no transcendental function, k_zr_zw
