@@ -162,19 +162,21 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 extern "C" {
 
 // returns 1 when launched: a closed level of <= 256 columns with nz = 2 (the coarsest grid of every BASELINE configuration) as one
-// wave, or of <= 1024 columns with nz = 2 / 4 (the 32x32x4 level above it) as four waves
+// wave, or of <= 1024 columns with nz = 2 / 4 (the 32x32x4 level above it) as four waves, or -- nz = 2 only -- of <= 2048 columns as
+// eight waves: the 64x32x2 coarsest grid that eight GPUs gather (4x2 ranks of 512x512x64: its 40 sweeps took 436 us in k_relax_small,
+// which re-reads every operand through L2, a fifth of a V-cycle on every rank)
 int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
-  static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr;
+  static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr, off8 = getenv("MGX_NO_WAVE8") != nullptr;
   if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (exact && method == 1 && real)) return 0;
   const int nblk = (L->nx / 2) * (L->ny / 2);
-  if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || nblk > 4 * WAVE) return 0;
+  if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || nblk > (L->nz == 2 && !off8 ? 8 : 4) * WAVE) return 0;
   if ((nblk > WAVE || L->nz == 4) && off4) return 0;
   const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
 #define WAVE_CASE(NZV, NTV)                                                                                                   \
   { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);      \
     else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);          \
     return mgx_launched(); }
-  if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else WAVE_CASE(2, 256) }
+  if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else if (nblk <= 4 * WAVE) WAVE_CASE(2, 256) else WAVE_CASE(2, 512) }
   if (nblk <= WAVE) WAVE_CASE(4, 64) else WAVE_CASE(4, 256)
 #undef WAVE_CASE
 }

@@ -636,12 +636,14 @@ int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int rea
   // fence-free form with sc1 stores and loads (measured on gfx950 only) -- the two time the same (F-cycle 283-285 vs 285 it/s)
   static const bool fence = getenv("MGX_KSP_SC1") == nullptr;
   if (off || nsweeps < 1 || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || (L->nx & 1) || L->ny / 2 > WAVE) return 0;
-  if ((L->nz != 16 && L->nz != 8) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
-  // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row
-  dim3 grd(L->nx), blk(WAVE, L->nz == 16 ? 4 : 8);
-#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 16 ? 4 : 8), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err, stall)
+  if ((L->nz != 16 && L->nz != 8 && L->nz != 4) || L->nx > 128 || done == nullptr || err == nullptr) return 0;
+  // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row;
+  // nz = 4: four waves of one row (the 128x64x4 level that eight GPUs gather; a single GPU's 32x32x4 level is k_relax_wave's)
+  dim3 grd(L->nx), blk(WAVE, L->nz == 8 ? 8 : 4);
+#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 8 ? 8 : 4), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err, stall)
   if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true); else KSP(16, true, false); } else { if (fence) KSP(16, false, true); else KSP(16, false, false); } }
-  else { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
+  else if (L->nz == 8) { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
+  else { if (real) { if (fence) KSP(4, true, true); else KSP(4, true, false); } else { if (fence) KSP(4, false, true); else KSP(4, false, false); } }
 #undef KSP
   return mgx_launched();
 }

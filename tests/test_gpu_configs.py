@@ -227,6 +227,23 @@ def test_config5_vcycle_512x1024x128_bitwise(mg):
     o.close()
 
 
+def test_coarse_levels_of_an_eight_gpu_run_bitwise(mg):
+    """What eight GPUs (4x2 ranks of 512x512x64, nsmall = 256) run redundantly after the gathers: the global coarse levels 256x128x8,
+    128x64x4 and the 64x32x2 coarsest grid with its 40 sweeps.  As a one-rank problem (256x128x8 -> 3 levels) every kernel that serves them
+    -- the colour-pair kernel (nx = 256 is beyond the persistent one), the persistent relax at nz = 4, the eight-wave one-workgroup
+    coarsest solve -- bit for bit against the oracle over three F-cycle iterations, every level's p."""
+    _gpu(mg, 256, 128, 8, relax_method="FC")
+    o = _oracle(256, 128, 8, relax_method="FC")
+    assert mg.nlevs() == o.nlevs == 3
+    n, hist = mg.solve_p(1e-30, 3)
+    no, ho, _ = o.solve_p(1e-30, 3)
+    assert n == no == 3 and _hist_close(hist, ho)
+    for lev in range(1, 4):
+        assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
+    g = mg.grid(3)
+    assert (g.nx, g.ny, g.nz) == (64, 32, 2)
+
+
 @pytest.mark.parametrize("nz", [64, 128])
 def test_level1_red_black_two_waves_per_block(mg, nz):
     """The level-1 kernels with TWO waves per workgroup (512 planes x 4 j-chunks = 2048 waves: red-black at 512x512; the LDS slices of

@@ -540,7 +540,7 @@ def test_fortran_harness_bmask(mg, tmp_path):
 
 
 @pytest.mark.parametrize("dims,par", [((128, 128, 16), {}), ((64, 128, 16), {}), ((96, 48, 16), {}), ((64, 64, 8), {}), ((128, 128, 16), {"cmatrix": "simple"}),
-                                      ((48, 96, 32), {"ns_pre": 1, "ns_post": 4})])
+                                      ((48, 96, 32), {"ns_pre": 1, "ns_post": 4}), ((128, 64, 4), {}), ((256, 128, 8), {})])
 def test_persistent_relax_equals_separate_launches(mg, dims, par):
     """The persistent mid-level relax (k_relax_ksp: one workgroup per plane for a whole relax call, planes handed between workgroups
     through per-plane progress counters) against one launch per colour pair (option "ksp" = 0): relax calls of 1..5 sweeps from a random
@@ -556,7 +556,7 @@ def test_persistent_relax_equals_separate_launches(mg, dims, par):
             got = []
             for lev in range(1, mg.nlevs() + 1):
                 g = mg.grid(lev)
-                if g.nz not in (8, 16) or g.ny > 128 or g.nx > 128:
+                if g.nz not in (4, 8, 16) or g.ny > 128 or g.nx > 128:
                     continue
                 p0 = rng.standard_normal(g._shape("p")); b0 = rng.standard_normal(g._shape("b"))
                 g.set("b", b0)
