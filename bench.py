@@ -217,6 +217,17 @@ def main():
         mg.compute_residual(1)
     sync()
     fc_rate = nf / (time.perf_counter() - t2)
+    # the same through solve_p itself (mg_solvers.f90:17-101: one host synchronisation per iteration, for the norm), p restored afterwards
+    p_keep_sp = mg.grid(1).p
+    nhydro.set_option("warm_start", 1)
+    sync()
+    t2b = time.perf_counter()
+    nsp = max(10, args.steps // 2)  # (the call's own set-up -- ||b|| and the first residual -- is 1 % of ten iterations)
+    mg.solve_p(1e-300, nsp)
+    sync()
+    sp_rate = nsp / (time.perf_counter() - t2b)
+    nhydro.set_option("warm_start", 0)
+    mg.grid(1).set("p", p_keep_sp)
 
     counters_main, nlev_main = nhydro.counters(), mg.nlevs()
     # the reference's default ordering (red-black) on the same workload, for the record (N=1 only)
@@ -285,6 +296,7 @@ def main():
                          "launch_ms": sweep_ms / ncol, "sweep_ms": sweep_ms},
             "residual_kernel": {"ms": resid_ms, "GBs": 88 * cells / (resid_ms * 1e-3) / 1e9},
             "fcycle_iterations_per_sec": fc_rate,
+            "solve_p_iterations_per_sec": sp_rate,
             "residual_before": res0, "residual_after": res1,
             "counters": counters_main,
             "also_rb": also_rb,

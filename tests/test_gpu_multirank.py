@@ -62,6 +62,7 @@ def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     (2, 2, 16, 16, 8, 8),      # the thread-rank machinery on a case the process-per-rank suite covers as well
     (4, 2, 16, 16, 128, 16),   # BASELINE config 5's process grid: 8 ranks, nz = 128, nsmall = 16 -> a 2x2 gather, then a 2x1 gather
     (4, 2, 32, 32, 16, 8),     # 4x2 with the gather on the last level only (2x1 after 2x2 ranks were halved once)
+    (4, 2, 64, 64, 16, 32),    # the shape of bench.py --gpus 8: two distributed levels, then 2x1 ranks with one open side, then one rank
 ])
 def test_config5_4x2_ranks_in_one_process(npx, npy, nx, ny, nz, nsmall):
     """BASELINE config 5 asks for a 4x2 decomposition with the coarse-grid gather (nsmall = 16).  The test box
