@@ -975,11 +975,6 @@ int halo_rank_coded_check(const char *who) {
   return 0;
 }
 
-void trim(std::string &s) {
-  size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n,");
-  s = (a == std::string::npos) ? "" : s.substr(a, b - a + 1);
-}
-
 }  // namespace
 
 // ====================================================================================================

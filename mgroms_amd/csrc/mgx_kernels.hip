@@ -573,10 +573,14 @@ __global__ __launch_bounds__(256) void k_halo_exchange(LevView L, double *__rest
   int q, k; long long e, t;
   for (int r = 0; r < pp.ipt; r++)
     if (halo_item(L, pp, dir, r, 0, q, k, e, t)) hx.rbuf[dir][t] = a[e];
-  __threadfence_system();  // this wave's remote writes are performed before the block reports in
+  // every storing wave drains its remote writes, the block meets, ONE lane issues the system-scope release before the block reports in
+  // (256 lanes fencing cost 2-4x one lane's: MI355X_MICROARCH.md, inter-workgroup visibility)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int ok;
   if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (__hip_atomic_fetch_add(pp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(pp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
@@ -679,9 +683,11 @@ __global__ void k_gather_push(LevView Cs, const double *__restrict__ js, GatherP
     const double v = js[(long long)i * Cs.plane + (long long)k * Cs.RS + jpos(Cs, j)];
     for (int q = 0; q < gp.ng; q++) gp.dst[q][t] = v;
   }
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // as k_halo_exchange: waves drain, the block meets, one lane releases at system scope
   __syncthreads();
   if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (__hip_atomic_fetch_add(gp.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
       __hip_atomic_store(gp.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
