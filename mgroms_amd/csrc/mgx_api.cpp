@@ -32,6 +32,7 @@ int mgxk_relax_ks_persist(hipStream_t, const LevView *, int, int, Sides, unsigne
 int mgxk_set_ksp_timeout(double);
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
+int mgxk_relax_wave_fused(hipStream_t, const LevView *, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 int mgxk_has_reg_kernel(const LevView *);
@@ -160,6 +161,7 @@ struct State {
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   int ksp_test_stall = 0;  // test hook (option "ksp_test_stall" = i): in the next persistent relax the workgroup of plane i returns at once
+  int use_fuse = 1;   // option "fuse_tail" / MGX_NO_WAVE_FUSE=1: coarse2fine / residual+restriction folded into the one-workgroup relax of the level below the coarsest (A/B)
   int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -633,14 +635,33 @@ int coarse2fine(int lev, bool keep_r = true, bool skip1 = false) {
   return 0;
 }
 
-// mg_solvers.f90:129-151
-int vcycle(int lev1) {
+// relax(lev, nsweeps) of the level below the coarsest one (a closed level the one-workgroup kernel serves), with coarse2fine(lev) folded
+// in front (flags & 1) and / or compute_residual(lev) + fine2coarse(lev) folded behind (flags & 2): mgx_relax_coarse.hip.  Returns 1 when
+// the fused kernel took the job (same bits as the separate operators), 0 = run them.
+int relax_fused(int lev, int nsweeps, int flags) {
+  if (lev >= S.nlevs || !S.use_small || !S.use_fuse || S.method == M_GS || S.tictoc || S.keep_r || S.exact_halos || !S.linear) return 0;
+  if (S.method == M_RB && S.real && S.rb_exact) return 0;
+  Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0}, phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0};
+  if (!all_physical(phf) || !all_physical(phc) || C.gather) return 0;
+  if (!mgxk_relax_wave_fused(S.stream, &F.v, &C.v, nsweeps, S.method, S.real, phf, flags)) return 0;
+  S.n_launch++;
+  if (flags & 1) F.r_halo_stale = true;  // what coarse2fine leaves (the correction is not stored in r inside a cycle)
+  return 1;
+}
+
+// mg_solvers.f90:129-151.  lead_c2f: the caller is Fcycle, whose coarse2fine(lev1) comes right before (:119-120)
+int vcycle(int lev1, bool lead_c2f = false) {
   for (int lev = lev1; lev <= S.nlevs - 1; lev++) {
+    const bool lead = lead_c2f && lev == lev1;
+    if (relax_fused(lev, S.par.ns_pre, lead ? 3 : 2)) continue;
+    if (lead) CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_pre >= 1));
     CHK(relax(lev, S.par.ns_pre));
     CHK(fine2coarse(lev, false, true));  // compute_residual(lev) + fine2coarse(lev)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
+    if (relax_fused(lev, S.par.ns_post, 1)) continue;
     CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_post >= 1));
     CHK(relax(lev, S.par.ns_post));
   }
@@ -668,10 +689,7 @@ int fcycle() {
     CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
-  for (int lev = S.nlevs - 1; lev >= 1; lev--) {
-    CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_pre >= 1));
-    CHK(vcycle(lev));
-  }
+  for (int lev = S.nlevs - 1; lev >= 1; lev--) CHK(vcycle(lev, true));  // coarse2fine(lev) + Vcycle(lev), :119-120
   return 0;
 }
 
@@ -1179,11 +1197,11 @@ void mgx_clean(void) {
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   if (S.kerr) (void)hipHostFree(S.kerr);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1471,6 +1489,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "ksp")) S.use_ksp = value;
+  else if (streq(name, "fuse_tail")) S.use_fuse = value;
   else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
   else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
@@ -1503,6 +1522,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "ksp")) *value = S.use_ksp;
+  else if (streq(name, "fuse_tail")) *value = S.use_fuse;
   else if (streq(name, "p2p_failed")) *value = S.p2p_failed;
   else if (streq(name, "p2p")) *value = S.p2p_on ? 1 : 0;
   else return fail("unknown option '%s'", name);

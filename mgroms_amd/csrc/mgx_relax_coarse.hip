@@ -16,8 +16,15 @@
 
 #include "mgx_device.h"
 
-template <int NZ, bool REAL, int NT>
-__global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph) {
+// flags (round 3; the level below the coarsest one in a cycle): 1 = coarse2fine(lev) first -- p += the tri-linear interpolation of the
+// coarse p of C (mg_intergrids.f90:366-450 + :226), applied while p is loaded into LDS; 2 = compute_residual(lev) + fine2coarse(lev)
+// afterwards (mg_relax.f90:421-515, mg_intergrids.f90:139-162, p_c = 0 :70) from the coefficients the lane holds anyway -- a lane's 2x2
+// block of columns is exactly one coarse column, so the 8-cell sum closes inside the lane.  Two launches less per level visit; the same
+// expressions in the same order as k_coarse2fine, k_residual and k_fine2coarse (the stored diagonal; the matrix-free kernels rebuild
+// the same bits).
+// FZ: the instance that can fold the transfers in (instantiated for nz = 4 only: the plain kernels keep their register budget)
+template <int NZ, bool REAL, int NT, bool FZ = false>
+__global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph, LevView C, int flags) {
   extern __shared__ double ldsw[];
   const int nx = G.nx, ny = G.ny, W = ny, PL = nx * ny;  // P[k][i-1][j-1], interior only
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
@@ -40,6 +47,33 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
     for (int k0 = 0; k0 < NZ; k0++)
 #pragma unroll
       for (int v = 0; v < 4; v++) tp[k0 * 4 + v] = cell[v] >= 0 ? LD32(G.p, cell[v] + k0 * G.RS) : 0.0;
+    if (FZ && (flags & 1)) {  // prolongation + correction: the fine cell (k,j,i) takes the coarse cell (k2,j2,i2) it lies in, that cell's neighbours
+                      // towards the fine cell's side (j-1 / i-1 for odd j / i, else j+1 / i+1) and the same four of level k2-1 (odd k) / k2+1
+      const double wa = 9. / 16., wb = 3. / 16., wc = 1. / 16., wd = 27. / 64., we = 9. / 64., wf = 3. / 64., wg = 1. / 64.;
+      const int cpl = (int)C.plane;
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        if (cell[v] < 0) continue;
+        const int r = lane + v * NT;
+        const int i = r / W + 1, j = r - (i - 1) * W + 1;
+        const int i2 = (i + 1) >> 1, j2 = (j + 1) >> 1, si = (i & 1) ? -1 : 1, sj = (j & 1) ? -1 : 1;
+        const int c00 = i2 * cpl + jpos(C, j2), cj_ = i2 * cpl + jpos(C, j2 + sj), ci_ = (i2 + si) * cpl + jpos(C, j2), cd_ = (i2 + si) * cpl + jpos(C, j2 + sj);
+#pragma unroll
+        for (int k0 = 0; k0 < NZ; k0++) {
+          const int k = k0 + 1, k2 = (k + 1) >> 1, ro = (k2 - 1) * C.RS;
+          const double x00 = LD32(C.p, c00 + ro), xd = LD32(C.p, cd_ + ro), xjn = LD32(C.p, cj_ + ro), xin = LD32(C.p, ci_ + ro);
+          double val;
+          if (k == 1) val = +wa * x00 + wc * xd + wb * xjn + wb * xin;
+          else if (k == NZ) val = 0.5 * (wa * x00 + wc * xd + wb * xjn + wb * xin);
+          else {
+            const int kp = k2 - ((k % 2) * 2 - 1), rp = (kp - 1) * C.RS;
+            const double y00 = LD32(C.p, c00 + rp), yd = LD32(C.p, cd_ + rp), yjn = LD32(C.p, cj_ + rp), yin = LD32(C.p, ci_ + rp);
+            val = +wd * x00 + wf * xd + we * xjn + we * xin + we * y00 + wg * yd + wf * yjn + wf * yin;
+          }
+          tp[k0 * 4 + v] = tp[k0 * 4 + v] + val;
+        }
+      }
+    }
 #pragma unroll
     for (int k0 = 0; k0 < NZ; k0++)
 #pragma unroll
@@ -138,6 +172,55 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
       __syncthreads();
     }
   }
+  if (FZ && (flags & 2) && mine) {
+    // compute_residual of the lane's four columns (stored slots, mg_relax.f90:464-509), then fine2coarse_3D: (k,jA,iA) + (k,jA,iB) + (k,jB,iA)
+    // + (k,jB,iB), then the same of k+1 (mg_intergrids.f90:149-160) -- columns q = 0, 2, 1, 3 of the block
+    double rr[4][NZ];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = 2 * bi + 1 + (q >> 1), j = 2 * bj + 1 + (q & 1);
+      const int oc = (i - 1) * W + (j - 1);
+      const int sjm = j > 1 ? -1 : 0, sjp = j < ny ? 1 : 0, sim = i > 1 ? -W : 0, sip = i < nx ? W : 0;
+      const int c0 = GI(0, j, i);
+      double pc[NZ], pjm[NZ], pjp[NZ], pim[NZ], pip[NZ], a1[NZ];
+#pragma unroll
+      for (int k = 0; k < NZ; k++) {
+        const int o = k * PL + oc;
+        pc[k] = P[o]; pjm[k] = P[o + sjm]; pjp[k] = P[o + sjp]; pim[k] = P[o + sim]; pip[k] = P[o + sip];
+        a1[k] = LD32(G.cA[0], c0 + k * G.RS);
+      }
+#pragma unroll
+      for (int k = 0; k < NZ; k++) {
+        double r;
+        if (k == 0) {
+          r = ob[q][k] - a1[k] * pc[k] - a2[q][k + 1] * pc[k + 1] - a3[q][k] * pjm[k + 1] - a4[q][k] * pjm[k] - R4(q, k) * pjp[k] - R5(q, k + 1) * pjp[k + 1]
+                       - a6[q][k] * pim[k + 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k] - R8(q, k + 1) * pip[k + 1];
+          if (REAL) r = r - a5[q][0] * P[oc + sim + sjp] - e2[q] * P[oc + sip + sjm] - a8[q][0] * P[oc + sim + sjm] - e4[q] * P[oc + sip + sjp];
+        } else if (k < NZ - 1) {
+          r = ob[q][k] - a1[k] * pc[k] - a2[q][k] * pc[k - 1] - a2[q][k + 1] * pc[k + 1] - a3[q][k] * pjm[k + 1] - R3(q, k - 1) * pjp[k - 1]
+                       - a4[q][k] * pjm[k] - R4(q, k) * pjp[k] - a5[q][k] * pjm[k - 1] - R5(q, k + 1) * pjp[k + 1]
+                       - a6[q][k] * pim[k + 1] - R6(q, k - 1) * pip[k - 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k]
+                       - a8[q][k] * pim[k - 1] - R8(q, k + 1) * pip[k + 1];
+        } else {
+          r = ob[q][k] - a1[k] * pc[k] - a2[q][k] * pc[k - 1] - R3(q, k - 1) * pjp[k - 1] - a4[q][k] * pjm[k] - R4(q, k) * pjp[k]
+                       - a5[q][k] * pjm[k - 1] - R6(q, k - 1) * pip[k - 1] - a7[q][k] * pim[k] - R7(q, k) * pip[k] - a8[q][k] * pim[k - 1];
+        }
+        rr[q][k] = r;
+      }
+    }
+    const int i2 = bi + 1, j2 = bj + 1, cjp = jpos(C, j2);
+    const long long oc2 = (long long)i2 * C.plane + cjp;
+#pragma unroll
+    for (int k2 = 0; k2 < NZ / 2; k2++) {
+      const int k = 2 * k2;
+      const double z = rr[0][k] + rr[2][k] + rr[1][k] + rr[3][k] + rr[0][k + 1] + rr[2][k + 1] + rr[1][k + 1] + rr[3][k + 1];
+      const long long rc = (long long)k2 * C.RS;
+      C.b[oc2 + rc] = z;
+      mirror_store(C, C.b, rc, j2, i2, cjp, z, ph);
+      C.p[oc2 + rc] = 0.0;
+      mirror_store(C, C.p, rc, j2, i2, cjp, 0.0, ph);
+    }
+  }
 #undef COLUMN
 #undef R3
 #undef R4
@@ -165,20 +248,43 @@ extern "C" {
 // wave, or of <= 1024 columns with nz = 2 / 4 (the 32x32x4 level above it) as four waves, or -- nz = 2 only -- of <= 2048 columns as
 // eight waves: the 64x32x2 coarsest grid that eight GPUs gather (4x2 ranks of 512x512x64: its 40 sweeps took 436 us in k_relax_small,
 // which re-reads every operand through L2, a fifth of a V-cycle on every rank)
-int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
+// Cv, flags: see k_relax_wave (0 / nullptr = the plain relax call); mgxk_relax_wave_fused is the entry the cycles use
+static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact, const LevView *Cv, int flags) {
   static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr, off8 = getenv("MGX_NO_WAVE8") != nullptr;
   if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (exact && method == 1 && real)) return 0;
   const int nblk = (L->nx / 2) * (L->ny / 2);
   if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || nblk > (L->nz == 2 && !off8 ? 8 : 4) * WAVE) return 0;
   if ((nblk > WAVE || L->nz == 4) && off4) return 0;
   const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
+  const LevView Cc = Cv ? *Cv : *L;
 #define WAVE_CASE(NZV, NTV)                                                                                                   \
-  { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);      \
-    else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph);          \
+  { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);      \
+    else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);          \
     return mgx_launched(); }
+#define WAVE_CASE_FZ(NTV)                                                                                                     \
+  { if (real) hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);  \
+    else hipLaunchKernelGGL((k_relax_wave<4, false, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);      \
+    return mgx_launched(); }
+  if (flags) {
+    if (L->nz != 4) return 0;
+    if (nblk <= WAVE) WAVE_CASE_FZ(64) else WAVE_CASE_FZ(256)
+  }
   if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else if (nblk <= 4 * WAVE) WAVE_CASE(2, 256) else WAVE_CASE(2, 512) }
   if (nblk <= WAVE) WAVE_CASE(4, 64) else WAVE_CASE(4, 256)
+#undef WAVE_CASE_FZ
 #undef WAVE_CASE
+}
+
+int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
+  return relax_wave_launch(st, L, nsweeps, method, real, ph, exact, nullptr, 0);
+}
+// relax(lev, nsweeps) of a closed level the one-workgroup kernel serves, with coarse2fine(lev) folded in front (flags & 1) and / or
+// compute_residual(lev) + fine2coarse(lev) folded behind (flags & 2); C = level lev+1 (closed, exactly half the size, not gathered).
+// Returns 1 when launched, 0 = the caller runs the separate operators.
+int mgxk_relax_wave_fused(hipStream_t st, const LevView *L, const LevView *C, int nsweeps, int method, int real, Sides ph, int flags) {
+  static const bool off = getenv("MGX_NO_WAVE_FUSE") != nullptr;
+  if (off || !C || C->nx * 2 != L->nx || C->ny * 2 != L->ny || C->nz * 2 != L->nz || nsweeps < 0) return 0;
+  return relax_wave_launch(st, L, nsweeps, method, real, ph, 0, C, flags);
 }
 
 }  // extern "C"

@@ -575,6 +575,43 @@ def test_persistent_relax_equals_separate_launches(mg, dims, par):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dims,par", [((64, 64, 16), {}), ((128, 128, 16), {}), ((96, 48, 16), {}), ((64, 32, 8), {}), ((64, 64, 16), {"relax_method": "RB", "cmatrix": "simple"}),
+                                      ((128, 128, 16), {"relax_method": "RB"}), ((64, 64, 16), {"ns_pre": 0, "ns_post": 1}), ((48, 96, 16), {"interp_type": "nearest"})])
+def test_fused_coarse_transfers_equal_separate_operators(mg, dims, par):
+    """On the level below the coarsest one the cycles fold coarse2fine in front of, and compute_residual + fine2coarse behind, the
+    one-workgroup relax kernel (option "fuse_tail", default 1).  A/B against the separate operators (0): every level's p and b after a
+    V-cycle from a random state, after Vcycle(nlevs-1), and after two F-cycle iterations, plus the history -- the same bits; with
+    parallel red-black too (both arms run the same parallel sweep); `nearest` interpolation keeps the separate operators."""
+    nx, ny, nz = dims
+    res = []
+    for fuse in (1, 0):
+        mg.nhydro.set_option("fuse_tail", fuse)
+        try:
+            _setup(mg, nx, ny, nz, **par)
+            nl = mg.nlevs()
+            rng = np.random.default_rng(21)
+            g = mg.grid(1)
+            g.set("p", rng.standard_normal(g._shape("p"))); mg.fill_halo(1, "p")
+            mg.nhydro.compute_rhs(*_uvw(nx, ny, nz, seed=9))
+            got = []
+            mg.Vcycle(1)
+            got += [mg.grid(l).p for l in range(1, nl + 1)] + [mg.grid(l).b for l in range(2, nl + 1)]
+            if nl >= 3:
+                mg.Vcycle(nl - 1)
+                got += [mg.grid(l).p for l in range(nl - 1, nl + 1)]
+            n, hist = mg.solve_p(1e-30, 2)
+            got += [mg.grid(l).p for l in range(1, nl + 1)] + [hist]
+            c = mg.nhydro.counters()["launches"]
+            res.append((got, c))
+        finally:
+            mg.nhydro.set_option("fuse_tail", 1)
+    assert len(res[0][0]) == len(res[1][0])
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    if par.get("interp_type") != "nearest":
+        assert res[0][1] < res[1][1]   # and it did take launches out
+
+
 def test_persistent_relax_timeout_falls_back(mg):
     """The persistent relax needs all its workgroups resident together.  If one never shows up (test hook: the workgroup of plane 5
     returns at once, as if a co-tenant of the GPU kept it off the chip) its neighbours' bounded polls expire (50 ms here, 2 s in
