@@ -493,7 +493,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
   }
   if (threadIdx.x == 0 && threadIdx.y == 0) s_bail = 0;
   __syncthreads();
+#ifdef MGX_KS_STAMP
+#define KSP_STAMP(q) { if (threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.x < 128 && s == 1) g_ks_stamp[blockIdx.x * 8 + (q)] = (long long)wall_clock64(); }
+#else
+#define KSP_STAMP(q)
+#endif
   for (int s = 0; s < nsweeps; s++) {
+    KSP_STAMP(0)
     // the addresses of a phase do not change from sweep to sweep: left alone, the compiler keeps all ~60 of them in registers across
     // the loop (and spills the coefficients instead); an opaque copy of the base pointer makes it rebuild them, a few scalar adds
     LevView Lc = L;
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
       __syncthreads();
       if (s_bail) return;
     }
+    KSP_STAMP(1)
     double pjm[R + 2] = {}, pjp[R + 2] = {}, d1 = 0, d2 = 0, d3 = 0, d4 = 0, bd1 = 0, bd2 = 0, bd3 = 0, bd4 = 0;
     if (live) {
 #pragma unroll
@@ -536,8 +543,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
     }
     if (live) ks_rhs<NZ, R, REAL>(A, pjm, pjp, d1, d2, d3, d4, ka, lane, sh, sa2, sbt);
     __syncthreads();
+    KSP_STAMP(2)
     if (w == 0 && live) ks_tridiag_lds<NZ>(sh, sa2, sbt, lane, xa, XS);
     __syncthreads();
+    KSP_STAMP(3)
     if (live) {
       ks_store<R, WT>(Lc, o, cA, i, 2 * lane + 1, ka, lane, xa, XS, ph);
       double qjm[R + 2], qjp[R + 2];
@@ -555,14 +564,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ksp(LevView L, int nsweeps
     __syncthreads();
     if (w == 0 && live) ks_tridiag_lds<NZ>(sh, sa2, sbt, lane, sh, WAVE);
     __syncthreads();
+    KSP_STAMP(4)
     if (live) ks_store<R, WT>(Lc, o, cB, i, 2 * lane + 2, ka, lane, sh, WAVE, ph);
     // publish: every storing wave drains its stores, the workgroup meets, one lane raises the plane's counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    KSP_STAMP(5)
     if (threadIdx.x == 0 && threadIdx.y == 0) {
       if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __hip_atomic_store(done + i, base + (unsigned int)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    KSP_STAMP(6)
   }
 }
 
