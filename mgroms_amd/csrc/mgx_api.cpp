@@ -62,6 +62,7 @@ void mgxk_gather_place_wait(hipStream_t, const LevView *, double *, const double
                             int *);
 void mgxs_coarsen2d(hipStream_t, const double *, double *, int, int, int, double);
 void mgxs_rect(hipStream_t, double *, double *, const RectOp *);
+void mgxs_halo_ref_closed(hipStream_t, double *, int, int, int, int);
 void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
 void mgxs_define_matrix(hipStream_t, const GeoView *, int lev1, int phase);
 void mgxs_pivots(hipStream_t, const LevView *);
@@ -348,6 +349,11 @@ int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c, bool xonly = fals
   const int *nb = L.neighb;
   const int So = nb[0], E = nb[1], N = nb[2], W = nb[3], SW = nb[4], SE = nb[5], NE = nb[6], NW = nb[7];
   const bool zSW = (c == 'u' && W < 0), zSE = (c == 'u' && E < 0), zNE = (c == 'u' && E < 0) || c == 'v', zNW = (c == 'u' && W < 0) || c == 'v';
+  if (!xonly && c == 0 && So < 0 && E < 0 && N < 0 && W < 0 && (nh == 1 || nh == 2) && nx >= 2 && ny >= 2) {
+    // no neighbour at all: every halo cell is an image (or, nh = 2, an extrapolation) of interior cells -- one launch for all sides and corners
+    mgxs_halo_ref_closed(S.stream, a, nzz, nh, ny, nx); S.n_launch++;
+    return 0;
+  }
   if (!xonly) {
   // phase 1: physical sides, in the reference's order S,E,N,W then the corners
   if (So < 0) {
@@ -796,7 +802,8 @@ int define_matrices() {
       }
     }
     mgxs_define_matrix(S.stream, &L.g, l == 0, 0); S.n_launch += 2;
-    if (S.par.bmask) CHK(rl_fill_halo(L, L.g.cA, 8 * L.nz, 1, 0, true));  // fill_halo(lev,cA), mg_define_matrix.f90:611-613
+    // fill_halo(lev,cA), mg_define_matrix.f90:611-613: the 4-D exchange, slot by slot (the set-up scratch is slot-major)
+    if (S.par.bmask) for (int s = 0; s < 8; s++) CHK(rl_fill_halo(L, L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), L.nz, 1, 0, true));
     mgxs_define_matrix(S.stream, &L.g, l == 0, 1); S.n_launch++;
     if (l == 0) {  // i-fastest copies for compute_rhs / correct_uvw (mgx_model.hip)
       mgxm_ref2model(S.stream, L.g.zw, L.g.mzw, L.nz + 1, 2, L.nx, L.ny);
@@ -810,7 +817,7 @@ int define_matrices() {
       S.n_launch += 8;
     }
     if (L.nz <= 128) { mgxk_convert8(S.stream, &L.v, L.g.cA); S.n_launch++; }  // 16 columns x nz x 8 slots in LDS (<= 131 KB)
-    else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA, 8, s, 0); S.n_launch++; }
+    else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), 1, 0, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;

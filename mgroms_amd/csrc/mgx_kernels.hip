@@ -627,23 +627,40 @@ __global__ void k_convert(LevView L, double *__restrict__ js, double *__restrict
   if (dir == 0) js[e] = ref[t * nslot + slot]; else ref[t * nslot + slot] = js[e];
 }
 
-// all 8 coefficient slots ref -> JS in one pass: a block takes TJ=16 consecutive columns of one plane, i.e. one contiguous
-// run of 16*nz*8 doubles of cA(8,k,j,i), stages it in LDS (column stride padded by one double) and writes every slot
-// row as 8 even-j + 8 odd-j neighbours (two 64-byte runs).
+// all 8 coefficient slots, set-up scratch -> JS, in one pass.  The scratch is SLOT-MAJOR (eight arrays (nz, 0:ny+1, 0:nx+1) one after
+// the other, mgx_setup.hip): a block takes TJ=16 consecutive columns of one plane, i.e. per slot one contiguous run of 16*nz doubles,
+// stages them in LDS (column stride padded by one double) and writes every slot row as 8 even-j + 8 odd-j neighbours (two 64-byte runs).
 struct Slots8 { double *s[8]; };
 __global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const double *__restrict__ ref) {
   extern __shared__ double lds[];
   constexpr int TJ = 16;
-  const int nz = L.nz, cs = nz * 8 + 1;
+  const int nz = L.nz, cs = nz + 1;   // LDS: [slot][column][k], k fastest, column stride padded by one double
   const int i = blockIdx.y, j0 = blockIdx.x * TJ;
   const int nj = min(TJ, L.ny + 2 - j0);
-  const double *__restrict__ src = ref + ((long long)i * (L.ny + 2) + j0) * nz * 8;
-  const int n = nj * nz * 8;
-  for (int t = threadIdx.x; t < n; t += blockDim.x) lds[(t / (nz * 8)) * cs + t % (nz * 8)] = src[t];
+  const long long n3 = (long long)nz * (L.ny + 2) * (L.nx + 2);
+  const double *__restrict__ src = ref + ((long long)i * (L.ny + 2) + j0) * nz;
+  const int run = nj * nz;
+  // no division of a flat index in the loops (the kernel was bound by that arithmetic, not by bytes): slot by slot; nz a power of two (every
+  // level of a power-of-two grid) turns the column / level split into a shift
+  const bool p2 = (nz & (nz - 1)) == 0;
+  const int lz = 31 - __builtin_clz(nz);
+#pragma unroll
+  for (int sl = 0; sl < 8; sl++) {
+    const double *__restrict__ ss = src + (long long)sl * n3;
+    for (int r = threadIdx.x; r < run; r += blockDim.x) {
+      const int jl = p2 ? (r >> lz) : r / nz, k = r - jl * nz;
+      lds[(sl * TJ + jl) * cs + k] = ss[r];
+    }
+  }
   __syncthreads();
-  for (int t = threadIdx.x; t < TJ * nz * 8; t += blockDim.x) {
-    const int jl = t % TJ, k = (t / TJ) % nz, sl = t / (TJ * nz);
-    if (jl < nj) out.s[sl][(long long)i * L.plane + (long long)k * L.RS + jpos(L, j0 + jl)] = lds[jl * cs + k * 8 + sl];
+  const long long ob = (long long)i * L.plane;
+#pragma unroll
+  for (int sl = 0; sl < 8; sl++) {
+    double *__restrict__ os = out.s[sl];
+    for (int t = threadIdx.x; t < TJ * nz; t += blockDim.x) {
+      const int jl = t & (TJ - 1), k = t >> 4;
+      if (jl < nj) os[ob + (long long)k * L.RS + jpos(L, j0 + jl)] = lds[(sl * TJ + jl) * cs + k];
+    }
   }
 }
 
@@ -861,7 +878,7 @@ void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int
 void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {
   Slots8 o;
   for (int q = 0; q < 8; q++) o.s[q] = L->cA[q];
-  const size_t lds = (size_t)16 * (L->nz * 8 + 1) * sizeof(double);
+  const size_t lds = (size_t)8 * 16 * (L->nz + 1) * sizeof(double);
   // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
   (void)hipFuncSetAttribute((const void *)k_convert8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_convert8, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);

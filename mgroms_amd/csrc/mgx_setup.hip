@@ -13,7 +13,10 @@
 #define I3(k, j, i) ((((long long)(i)) * (ny + 2) + (j)) * nz + ((k)-1))
 #define I3P(k, j, i) ((((long long)(i)) * (ny + 2) + (j)) * (nz + 1) + ((k)-1))
 #define CW(k, j, i) G.cw[I3P(k, j, i)]
-#define CA(s, k, j, i) G.cA[I3(k, j, i) * 8 + ((s)-1)]
+// set-up scratch of the eight slots: SLOT-MAJOR, eight arrays (nz, 0:ny+1, 0:nx+1) one after the other.  (The reference's record layout
+// cA(8,k,j,i) made every store of a k-lane wave hit 64 different 64-byte records with 8 bytes each: 2.2 GB written for 0.8 GB of
+// coefficients at 512x512x64, counters of round 3; slot-major a wave writes one 512-byte run per slot.)
+#define CA(s, k, j, i) G.cA[(long long)((s)-1) * ((long long)nz * (ny + 2) * (nx + 2)) + I3(k, j, i)]
 
 // umask(j,i) = rmask(j,i-1)*rmask(j,i) for i>=1, vmask(j,i) = rmask(j-1,i)*rmask(j,i) for j>=1, 0 elsewhere; all 1 without bmask
 #define RMK(j, i) A2(G.rmask, j, i)
@@ -32,12 +35,14 @@
 #define KCOL_THREAD(nk, jlo, jhi, ilo, ihi)                                   \
   const int nx = G.nx, ny = G.ny, nz = G.nz;                                  \
   (void)nx; (void)ny; (void)nz;                                               \
-  const long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
-  const int k = 1 + (int)(t_ % (nk));                                         \
-  const long long c_ = t_ / (nk);                                             \
-  const int nj_ = (jhi) - (jlo) + 1;                                          \
-  const int j = (jlo) + (int)(c_ % nj_);                                      \
-  const int i = (ilo) + (int)(c_ / nj_);                                      \
+  /* 32-bit index arithmetic (a level has < 2^31 cells): the 64-bit divisions of a flat index were a quarter of these kernels' */ \
+  /* instructions (they are bound by the count of vector instructions: counters of round 3) */ \
+  const unsigned t_ = blockIdx.x * blockDim.x + threadIdx.x;                  \
+  const unsigned nk_ = (unsigned)(nk), c_ = t_ / nk_;                         \
+  const int k = 1 + (int)(t_ - c_ * nk_);                                     \
+  const unsigned nj_ = (unsigned)((jhi) - (jlo) + 1), ci_ = c_ / nj_;         \
+  const int j = (jlo) + (int)(c_ - ci_ * nj_);                                \
+  const int i = (ilo) + (int)ci_;                                             \
   if (i > (ihi)) return;
 
 // mg_define_matrix.f90:116-138: dx,dy = 1/2 sum4 ; zeta,h = 1/4 sum4.  dst is (0:nyc+1,0:nxc+1)
@@ -75,14 +80,50 @@ __global__ void k_rect(double *__restrict__ a, double *__restrict__ buf, RectOp 
 #undef AI
 }
 
-// mg_zr_zw.f90:98-170 setup_zr_zw_croco, 'new_s_coord', computed on 0:n+1 (:91)
+// fill_halo_2D / fill_halo_3D of a reference-layout array a(nzz, 1-nh:ny+nh, 1-nh:nx+nh) on a level WITHOUT neighbours (every side physical,
+// mg_mpi_exchange.f90:509-537 edges, :552-597 corners, :956-964 the nh = 2 extrapolation) in ONE launch: every halo cell's sources are
+// interior cells, so the reference's order S, E, N, W, corners does not matter.  (As k_rect operations a fill was 8-12 launches of a few
+// hundred threads; 341 launches, 0.9 ms, per rebuild of the 512x512x64 hierarchy.)  One thread per halo cell and level k.
+__global__ void k_halo_ref_closed(double *__restrict__ a, int nzz, int nh, int ny, int nx) {
+  const unsigned W = ny + 2 * nh, band = nh * W, ring = 2 * band + (unsigned)nx * 2 * nh;
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned r = t / nzz;
+  if (r >= ring) return;
+  const int k = (int)(t - r * nzz);
+  int j, i;
+  if (r < band) { i = 1 - nh + (int)(r / W); j = 1 - nh + (int)(r % W); }
+  else if (r < 2 * band) { const unsigned q = r - band; i = nx + 1 + (int)(q / W); j = 1 - nh + (int)(q % W); }
+  else { const unsigned q = r - 2 * band, ii = q / (2 * nh), jj = q - ii * 2 * nh; i = 1 + (int)ii; j = (int)jj < nh ? 1 - nh + (int)jj : ny + 1 + ((int)jj - nh); }
+#define AI(jj, ii) ((((long long)((ii) + nh - 1)) * W + ((jj) + nh - 1)) * nzz + k)
+  const bool jin = j >= 1 && j <= ny, iin = i >= 1 && i <= nx;
+  double v;
+  if (iin) {        // south / north edge
+    if (j == 0) v = a[AI(1, i)];
+    else if (j < 0) v = 2.0 * a[AI(1, i)] - a[AI(2, i)];
+    else if (j == ny + 1) v = a[AI(ny, i)];
+    else v = 2.0 * a[AI(ny, i)] - a[AI(ny - 1, i)];
+  } else if (jin) {  // west / east edge
+    if (i == 0) v = a[AI(j, 1)];
+    else if (i < 0) v = 2.0 * a[AI(j, 1)] - a[AI(j, 2)];
+    else if (i == nx + 1) v = a[AI(j, nx)];
+    else v = 2.0 * a[AI(j, nx)] - a[AI(j, nx - 1)];
+  } else {          // corner where both sides are physical: the diagonal mirror
+    const int sj = j <= 0 ? 1 - j : 2 * ny + 1 - j, si = i <= 0 ? 1 - i : 2 * nx + 1 - i;
+    v = a[AI(sj, si)];
+  }
+  a[AI(j, i)] = v;
+#undef AI
+}
+
+// mg_zr_zw.f90:98-170 setup_zr_zw_croco, 'new_s_coord', computed on 0:n+1 (:91).  Lanes run along k, the fastest index of zr / zw: a
+// wave writes whole k-runs (with a lane per column every store hit 64 lines: 1.3 GB written for 0.27 GB of depths, counters of round 3).
 __global__ void k_zr_zw(GeoView G, double hlim, double theta_b, double theta_s) {
-  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
+  KCOL_THREAD(G.nz + 1, 0, G.ny + 1, 0, G.nx + 1)
   const double one = 1.0, hlf = 0.5, nul = 0.0;
   const double cff = one / (double)nz;
   const double h = A2(G.h, j, i), zeta = A2(G.zeta, j, i);
   const double hinv = one / (h + hlim);
-  for (int k = 1; k <= nz + 1; k++) {
+  {
     double cswf, cs_w;
     const double sc_w = cff * (double)(k - 1 - nz);
     if (theta_s > nul) cswf = (one - cosh(theta_s * sc_w)) / (cosh(theta_s) - one); else cswf = -(sc_w * sc_w);
@@ -356,8 +397,12 @@ void mgxs_rect(hipStream_t st, double *a, double *buf, const RectOp *R) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_rect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, buf, *R);
 }
+void mgxs_halo_ref_closed(hipStream_t st, double *a, int nzz, int nh, int ny, int nx) {
+  const long long n = (long long)nzz * (2LL * nh * (ny + 2 * nh) + 2LL * nh * nx);
+  hipLaunchKernelGGL(k_halo_ref_closed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, nzz, nh, ny, nx);
+}
 void mgxs_zr_zw(hipStream_t st, const GeoView *G, double hlim, double theta_b, double theta_s) {
-  hipLaunchKernelGGL(k_zr_zw, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, hlim, theta_b, theta_s);
+  hipLaunchKernelGGL(k_zr_zw, kgrid(G->nz + 1, G->ny + 2, G->nx + 2), dim3(256), 0, st, *G, hlim, theta_b, theta_s);
 }
 void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
   if (phase == 0) {
