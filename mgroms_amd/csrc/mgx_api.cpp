@@ -66,7 +66,8 @@ void mgxs_halo_ref_closed(hipStream_t, double *, int, int, int, int);
 void mgxs_zr_zw(hipStream_t, const GeoView *, double, double, double);
 void mgxs_define_matrix(hipStream_t, const GeoView *, int lev1, int phase);
 void mgxs_pivots(hipStream_t, const LevView *);
-void mgxs_slopes_js(hipStream_t, const GeoView *, const LevView *);
+void mgxs_slopes_ref(hipStream_t, const GeoView *);
+void mgxk_convert2(hipStream_t, const LevView *, double *, double *, const double *);
 void mgxs_zw_js(hipStream_t, const GeoView *, const LevView *, double, double, double);
 void mgxm_ref2model(hipStream_t, const double *, double *, int rows, int nh, int nx, int ny);
 void mgxm_ref2model_2d(hipStream_t, const double *, double *, int nx, int ny);
@@ -134,6 +135,7 @@ struct State {
   double *d_partial = nullptr; int npartial = 0;
   double *d_scalar = nullptr; double *h_scalar = nullptr;
   double *ref_scratch = nullptr; size_t ref_scratch_n = 0;  // reference-layout staging (8 x level-1 field)
+  double *slope_scratch = nullptr;                          // zy, zx of the level in work (2 x level-1 field), mgx_setup.hip
   double *xbuf[16]; size_t xbuf_n = 0;                       // 8 send + 8 receive halo buffers
   // peer-to-peer halo transport (mgx_p2p_prepare / mgx_p2p_connect): receive slab + flags in fine-grained device memory,
   // the same slab and flags of every other rank opened through hipIpc
@@ -801,6 +803,8 @@ int define_matrices() {
         if (L.neighb[3] < 0) rect(L.g.rmask, 0, 2, 1, 1, L.ny, 0, L.ny + 1, 0, 0);
       }
     }
+    L.g.szx = L.g.szy + (size_t)L.nz * (L.ny + 2) * (L.nx + 2);
+    mgxs_slopes_ref(S.stream, &L.g); S.n_launch++;  // zy, zx once per cell: the cross coefficients and the smoother's matrix-free slopes both come from here
     mgxs_define_matrix(S.stream, &L.g, l == 0, 0); S.n_launch += 2;
     // fill_halo(lev,cA), mg_define_matrix.f90:611-613: the 4-D exchange, slot by slot (the set-up scratch is slot-major)
     if (S.par.bmask) for (int s = 0; s < 8; s++) CHK(rl_fill_halo(L, L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), L.nz, 1, 0, true));
@@ -820,7 +824,8 @@ int define_matrices() {
     else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), 1, 0, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
-    mgxs_slopes_js(S.stream, &L.g, &L.v); S.n_launch++;
+    if (L.nz <= 1024) { mgxk_convert2(S.stream, &L.v, L.zy_store, L.zx_store, L.g.szy); S.n_launch++; }
+    else { mgxk_convert(S.stream, &L.v, L.zy_store, L.g.szy, 1, 0, 0); mgxk_convert(S.stream, &L.v, L.zx_store, L.g.szx, 1, 0, 0); S.n_launch += 2; }
     L.v.m4 = L.f2d_store[0]; L.v.d4 = L.f2d_store[1]; L.v.m7 = L.f2d_store[2]; L.v.d7 = L.f2d_store[3];
     L.v.h2 = L.f2d_store[4]; L.v.hi2 = L.f2d_store[5]; L.v.ze2 = L.f2d_store[6]; L.v.cffw = L.tab_store[0]; L.v.csw = L.tab_store[1];
     L.v.dx2 = L.zg_store[0]; L.v.dy2 = L.zg_store[1]; L.v.cffr = L.zg_store[2]; L.v.csr = L.zg_store[3];
@@ -1303,7 +1308,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   Level &L1 = S.lev[0];
   S.ref_scratch_n = (size_t)8 * L1.nz * (L1.ny + 2) * (L1.nx + 2);
   CHK(dmalloc(&S.ref_scratch, S.ref_scratch_n));
-  for (auto &L : S.lev) L.g.cA = S.ref_scratch;
+  CHK(dmalloc(&S.slope_scratch, S.ref_scratch_n / 4));  // 2 x level-1 field: the slopes zy, zx in the reference layout
+  for (auto &L : S.lev) { L.g.cA = S.ref_scratch; L.g.szy = S.slope_scratch; L.g.szx = nullptr; }
   S.xbuf_n = (size_t)(L1.nz + 1) * 2 * ((L1.nx > L1.ny ? L1.nx : L1.ny) + 4);
   if (S.par.bmask && S.nranks > 1) {  // the 4-D cA halo of define_matrix travels through the same buffers
     const size_t n4 = (size_t)8 * L1.nz * (L1.nx > L1.ny ? L1.nx : L1.ny);

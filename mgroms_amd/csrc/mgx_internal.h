@@ -42,7 +42,8 @@ struct GeoView {
   double *zr;                  // (nz,   -1:ny+2, -1:nx+2)
   double *zw;                  // (nz+1, -1:ny+2, -1:nx+2)
   double *cw;                  // (nz+1, 0:ny+1, 0:nx+1)
-  double *cA;                  // (8, nz, 0:ny+1, 0:nx+1)   scratch shared by all levels
+  double *cA;                  // set-up scratch shared by all levels: SLOT-MAJOR, eight arrays (nz, 0:ny+1, 0:nx+1) one after the other
+  double *szy, *szx;           // slopes zy, zx (nz, 0:ny+1, 0:nx+1), scratch shared by all levels (szx = szy + the level's array size)
   double *dzw, *zxdy, *zydx;   // level 1 only
   double *mzw, *mdzw, *mzxdy, *mzydx, *mcw, *mdx, *mdy, *mrmask;  // level 1 only: i-fastest copies read by compute_rhs / correct_uvw (mgx_model.hip)
   double *rmask;               // (0:ny+1, 0:nx+1) boundary / land mask of the level (mg_define_matrix.f90:78-79,157-161)

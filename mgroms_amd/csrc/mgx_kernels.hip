@@ -631,6 +631,7 @@ __global__ void k_convert(LevView L, double *__restrict__ js, double *__restrict
 // the other, mgx_setup.hip): a block takes TJ=16 consecutive columns of one plane, i.e. per slot one contiguous run of 16*nz doubles,
 // stages them in LDS (column stride padded by one double) and writes every slot row as 8 even-j + 8 odd-j neighbours (two 64-byte runs).
 struct Slots8 { double *s[8]; };
+template <int NS>
 __global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const double *__restrict__ ref) {
   extern __shared__ double lds[];
   constexpr int TJ = 16;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const d
   const bool p2 = (nz & (nz - 1)) == 0;
   const int lz = 31 - __builtin_clz(nz);
 #pragma unroll
-  for (int sl = 0; sl < 8; sl++) {
+  for (int sl = 0; sl < NS; sl++) {
     const double *__restrict__ ss = src + (long long)sl * n3;
     for (int r = threadIdx.x; r < run; r += blockDim.x) {
       const int jl = p2 ? (r >> lz) : r / nz, k = r - jl * nz;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const d
   __syncthreads();
   const long long ob = (long long)i * L.plane;
 #pragma unroll
-  for (int sl = 0; sl < 8; sl++) {
+  for (int sl = 0; sl < NS; sl++) {
     double *__restrict__ os = out.s[sl];
     for (int t = threadIdx.x; t < TJ * nz; t += blockDim.x) {
       const int jl = t & (TJ - 1), k = t >> 4;
@@ -880,8 +881,17 @@ void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {
   for (int q = 0; q < 8; q++) o.s[q] = L->cA[q];
   const size_t lds = (size_t)8 * 16 * (L->nz + 1) * sizeof(double);
   // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
-  (void)hipFuncSetAttribute((const void *)k_convert8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_convert8, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
+  (void)hipFuncSetAttribute((const void *)k_convert8<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_convert8<8>, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
+}
+// two slot-major arrays (nz, 0:ny+1, 0:nx+1) at ref, ref + n3 -> the JS arrays out0, out1 (the slopes zy, zx)
+void mgxk_convert2(hipStream_t st, const LevView *L, double *out0, double *out1, const double *ref) {
+  Slots8 o;
+  for (int q = 0; q < 8; q++) o.s[q] = nullptr;
+  o.s[0] = out0; o.s[1] = out1;
+  const size_t lds = (size_t)2 * 16 * (L->nz + 1) * sizeof(double);
+  (void)hipFuncSetAttribute((const void *)k_convert8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_convert8<2>, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
 }
 void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m) {
   const long long n = (long long)C->nz * nyc * nxc;

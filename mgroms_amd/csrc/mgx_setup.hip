@@ -45,6 +45,23 @@
   const int i = (ilo) + (int)ci_;                                             \
   if (i > (ihi)) return;
 
+// The same for kernels whose first and last level have formulas of their own (k_cA_offdiag, k_cA_diag): with k simply along the lanes every
+// wave holds one lane of each special row and runs their long branches for it (the interior rows were a third of k_cA_offdiag's time).
+// Here the first nint = nz - 2 rows x columns threads are the interior rows 2 .. nz-1 (k along the lanes), the remaining 2 x columns
+// threads the rows 1 and nz (columns along the lanes): a wave runs one branch.  Launch with kgrid(nz, nj, ni) as before.
+#define KCOL_THREAD_ENDS(jlo, jhi, ilo, ihi)                                  \
+  const int nx = G.nx, ny = G.ny, nz = G.nz;                                  \
+  (void)nx; (void)ny; (void)nz;                                               \
+  const unsigned t_ = blockIdx.x * blockDim.x + threadIdx.x;                  \
+  const unsigned nj_ = (unsigned)((jhi) - (jlo) + 1), ni_ = (unsigned)((ihi) - (ilo) + 1), ncol_ = nj_ * ni_;  \
+  const unsigned nint_ = (unsigned)(nz - 2), tint_ = nint_ * ncol_;           \
+  unsigned c_; int k;                                                         \
+  if (t_ < tint_) { c_ = t_ / nint_; k = 2 + (int)(t_ - c_ * nint_); }        \
+  else { const unsigned e_ = t_ - tint_, w_ = e_ / ncol_; if (w_ > 1) return; c_ = e_ - w_ * ncol_; k = w_ ? nz : 1; }  \
+  const unsigned ci_ = c_ / nj_;                                              \
+  const int j = (jlo) + (int)(c_ - ci_ * nj_);                                \
+  const int i = (ilo) + (int)ci_;
+
 // mg_define_matrix.f90:116-138: dx,dy = 1/2 sum4 ; zeta,h = 1/4 sum4.  dst is (0:nyc+1,0:nxc+1)
 __global__ void k_coarsen2d(const double *__restrict__ src, double *__restrict__ dst, int nyf, int nyc, int nxc, double fac) {
   const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -163,11 +180,24 @@ __global__ void k_cw(GeoView G, int lev1) {
   CW(k, j, i) = (Arz / den) * (one + sx * sx + sy * sy);
 }
 
+// The slopes every cross coefficient is built from, once per cell with the reference's inline expression
+//   zy(k,j,i) = ( hlf*(zr(k,j+1,i)-zr(k,j-1,i)) / dy(j,i) ) * dx(j,i) ,  zx likewise in i        (mg_define_matrix.f90:358, 398)
+// on 0:n+1.  k_cA_offdiag used to evaluate these quotients up to ten times per cell (it is bound by its vector-instruction count: 1360
+// per wave, counters of round 3); the smoother's matrix-free slopes (LevView zy / zx) are a layout conversion of the same two arrays.
+#define SZY(k, j, i) G.szy[I3(k, j, i)]
+#define SZX(k, j, i) G.szx[I3(k, j, i)]
+__global__ void k_slopes_ref(GeoView G) {
+  KCOL_THREAD(G.nz, 0, G.ny + 1, 0, G.nx + 1)
+  const double hlf = 0.5;
+  SZY(k, j, i) = (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
+  SZX(k, j, i) = (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
+}
+
 // mg_define_matrix.f90:352-609: off-diagonal slots (bmask = .false., umask = vmask = 1).
 // Loop ranges of the reference: slots 3,4,5(k>1): i=1..nx, j=1..ny+1 ; slots 6,7,8(k>1): i=1..nx+1, j=1..ny ;
 // cA(5,1): i=1..nx+1, j=0..ny ; cA(8,1): i=1..nx+1, j=1..ny+1 ; cA(2): interior.
 __global__ void k_cA_offdiag(GeoView G) {
-  KCOL_THREAD(G.nz, 0, G.ny + 1, 1, G.nx + 1)
+  KCOL_THREAD_ENDS(0, G.ny + 1, 1, G.nx + 1)
   const double one = 1.0, qrt = 0.25, hlf = 0.5;
   const bool in345 = (i <= nx) && (j >= 1);
   const bool in678 = (j >= 1) && (j <= ny);
@@ -240,21 +270,17 @@ __global__ void k_cA_offdiag(GeoView G) {
             - qrt * ((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i) -
                      (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i)) * (VM(j + 1, i) - VM(j, i));
     }
-    if (in345) {
-      CA(3, k, j, i) = qrt * ((hlf * (ZR(k + 1, j + 1, i) - ZR(k + 1, j - 1, i)) / DY(j, i)) * DX(j, i) +
-                              (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)) * VM(j, i);
+    if (in345) {  // the slope terms are the stored zy (same expression, evaluated once per cell by k_slopes_ref)
+      CA(3, k, j, i) = qrt * (SZY(k + 1, j, i) + SZY(k, j - 1, i)) * VM(j, i);
       CA(4, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j - 1, i) - ZW(k, j - 1, i)) *
                         (DX(j, i) + DX(j - 1, i))) / (hlf * (DY(j, i) + DY(j - 1, i))) * VM(j, i);
-      CA(5, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j + 1, i) - ZR(k - 1, j - 1, i)) / DY(j, i)) * DX(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i))) * VM(j, i);
+      CA(5, k, j, i) = -qrt * ((SZY(k - 1, j, i)) + (SZY(k, j - 1, i))) * VM(j, i);
     }
     if (in678) {
-      CA(6, k, j, i) = qrt * (((hlf * (ZR(k + 1, j, i + 1) - ZR(k + 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                              ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
+      CA(6, k, j, i) = qrt * ((SZX(k + 1, j, i)) + (SZX(k, j, i - 1))) * UM(j, i);
       CA(7, k, j, i) = (qrt * (ZW(k + 1, j, i) - ZW(k, j, i) + ZW(k + 1, j, i - 1) - ZW(k, j, i - 1)) *
                         (DY(j, i) + DY(j, i - 1))) / (hlf * (DX(j, i) + DX(j, i - 1))) * UM(j, i);
-      CA(8, k, j, i) = -qrt * (((hlf * (ZR(k - 1, j, i + 1) - ZR(k - 1, j, i - 1)) / DX(j, i)) * DY(j, i)) +
-                               ((hlf * (ZR(k, j, i) - ZR(k, j, i - 2)) / DX(j, i - 1)) * DY(j, i - 1))) * UM(j, i);
+      CA(8, k, j, i) = -qrt * ((SZX(k - 1, j, i)) + (SZX(k, j, i - 1))) * UM(j, i);
     }
   } else {
   if (in345 && j <= ny) CA(2, k, j, i) = CW(k, j, i);
@@ -281,7 +307,7 @@ __global__ void k_cA_offdiag(GeoView G) {
 
 // mg_define_matrix.f90:616-657: diagonal, interior columns
 __global__ void k_cA_diag(GeoView G) {
-  KCOL_THREAD(G.nz, 1, G.ny, 1, G.nx)
+  KCOL_THREAD_ENDS(1, G.ny, 1, G.nx)
   const double hlf = 0.5;
   if (k == 1)
   CA(1, k, j, i) = -CA(2, k + 1, j, i) - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
@@ -300,18 +326,6 @@ __global__ void k_cA_diag(GeoView G) {
                    - hlf * (hlf * (ZR(k, j, i) - ZR(k, j - 2, i)) / DY(j - 1, i)) * DX(j - 1, i)
                    - CA(4, k, j, i) - CA(4, k, j + 1, i) - CA(7, k, j, i) - CA(7, k, j, i + 1)
                    - CA(6, k - 1, j, i + 1) - CA(8, k, j, i) - CA(3, k - 1, j + 1, i) - CA(5, k, j, i);
-}
-
-// slopes for the matrix-free cross terms of the smoother, in the JS layout, with the reference's inline expression
-// ( hlf * (zr(k,j+1,i)-zr(k,j-1,i)) / dy(j,i) ) * dx(j,i)   (mg_define_matrix.f90:358, 398)
-__global__ void k_slopes_js(GeoView G, LevView L) {
-  COLUMN_THREAD(0, G.ny + 1, 0, G.nx + 1)
-  const double hlf = 0.5;
-  const long long o = (long long)i * L.plane + jpos(L, j);
-  for (int k = 1; k <= nz; k++) {
-    L.zy[o + (long long)(k - 1) * L.RS] = (hlf * (ZR(k, j + 1, i) - ZR(k, j - 1, i)) / DY(j, i)) * DX(j, i);
-    L.zx[o + (long long)(k - 1) * L.RS] = (hlf * (ZR(k, j, i + 1) - ZR(k, j, i - 1)) / DX(j, i)) * DY(j, i);
-  }
 }
 
 // What the colour pass needs to rebuild the interior rows of slots 4 and 7 instead of streaming them (mg_define_matrix.f90:532-534,
@@ -412,7 +426,7 @@ void mgxs_define_matrix(hipStream_t st, const GeoView *G, int lev1, int phase) {
     hipLaunchKernelGGL(k_cA_diag, kgrid(G->nz, G->ny, G->nx), dim3(256), 0, st, *G);
   }
 }
-void mgxs_slopes_js(hipStream_t st, const GeoView *G, const LevView *L) { hipLaunchKernelGGL(k_slopes_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L); }
+void mgxs_slopes_ref(hipStream_t st, const GeoView *G) { hipLaunchKernelGGL(k_slopes_ref, kgrid(G->nz, G->ny + 2, G->nx + 2), dim3(256), 0, st, *G); }
 void mgxs_zw_js(hipStream_t st, const GeoView *G, const LevView *L, double hlim, double theta_b, double theta_s) {
   hipLaunchKernelGGL(k_zw_js, cgrid(G->ny + 2, G->nx + 2), CBLK, 0, st, *G, *L, hlim);
   hipLaunchKernelGGL(k_sigma_tables, dim3((G->nz + 1 + 63) / 64), dim3(64), 0, st, G->nz, hlim, theta_b, theta_s, (double *)L->cffw, (double *)L->csw);
