@@ -820,7 +820,7 @@ int define_matrices() {
       mgxm_ref2model_2d(S.stream, L.g.rmask, L.g.mrmask, L.nx, L.ny);
       S.n_launch += 8;
     }
-    if (L.nz <= 128) { mgxk_convert8(S.stream, &L.v, L.g.cA); S.n_launch++; }  // 16 columns x nz x 8 slots in LDS (<= 131 KB)
+    if (L.nz <= 1024) { mgxk_convert8(S.stream, &L.v, L.g.cA); S.n_launch++; }  // LDS-tiled transposition, one slot per block
     else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), 1, 0, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;

@@ -627,41 +627,42 @@ __global__ void k_convert(LevView L, double *__restrict__ js, double *__restrict
   if (dir == 0) js[e] = ref[t * nslot + slot]; else ref[t * nslot + slot] = js[e];
 }
 
-// all 8 coefficient slots, set-up scratch -> JS, in one pass.  The scratch is SLOT-MAJOR (eight arrays (nz, 0:ny+1, 0:nx+1) one after
-// the other, mgx_setup.hip): a block takes TJ=16 consecutive columns of one plane, i.e. per slot one contiguous run of 16*nz doubles,
-// stages them in LDS (column stride padded by one double) and writes every slot row as 8 even-j + 8 odd-j neighbours (two 64-byte runs).
+// Set-up scratch -> JS for NS slot-major arrays (nz, 0:ny+1, 0:nx+1) at ref, ref + n3, ... (the eight coefficient slots; the two slope
+// arrays).  A block takes one slot (blockIdx.z), one plane and TJ consecutive columns: one contiguous run of TJ*nz doubles, staged in
+// LDS with the even and the odd columns apart ([parity][column pair][k], column stride padded by one double), then written row by row:
+// for every k one wave stores TJ/2 consecutive even-j entries and one TJ/2 consecutive odd-j entries -- 512-byte runs at TJ = 128
+// (the first version moved all eight slots of 16 columns per block: 64-byte runs, 2.1 TB/s at 512x512x64).
 struct Slots8 { double *s[8]; };
-template <int NS>
-__global__ __launch_bounds__(256) void k_convert8(LevView L, Slots8 out, const double *__restrict__ ref) {
+__global__ __launch_bounds__(256) void k_convert_slots(LevView L, Slots8 out, const double *__restrict__ ref, int TJ) {
   extern __shared__ double lds[];
-  constexpr int TJ = 16;
-  const int nz = L.nz, cs = nz + 1;   // LDS: [slot][column][k], k fastest, column stride padded by one double
-  const int i = blockIdx.y, j0 = blockIdx.x * TJ;
+  const int nz = L.nz, cs = nz + 1, H = (TJ >> 1) * cs;
+  const int i = blockIdx.y, j0 = blockIdx.x * TJ, sl = blockIdx.z;
   const int nj = min(TJ, L.ny + 2 - j0);
   const long long n3 = (long long)nz * (L.ny + 2) * (L.nx + 2);
-  const double *__restrict__ src = ref + ((long long)i * (L.ny + 2) + j0) * nz;
+  const double *__restrict__ src = ref + (long long)sl * n3 + ((long long)i * (L.ny + 2) + j0) * nz;
   const int run = nj * nz;
-  // no division of a flat index in the loops (the kernel was bound by that arithmetic, not by bytes): slot by slot; nz a power of two (every
-  // level of a power-of-two grid) turns the column / level split into a shift
   const bool p2 = (nz & (nz - 1)) == 0;
   const int lz = 31 - __builtin_clz(nz);
+  // eight loads in flight per thread before the first LDS store (one load per iteration made the block a chain of 32 memory round trips)
+  constexpr int U = 8;
+  const int nt = blockDim.x;
+  for (int r0 = threadIdx.x; r0 < run; r0 += U * nt) {
+    double v[U];
 #pragma unroll
-  for (int sl = 0; sl < NS; sl++) {
-    const double *__restrict__ ss = src + (long long)sl * n3;
-    for (int r = threadIdx.x; r < run; r += blockDim.x) {
-      const int jl = p2 ? (r >> lz) : r / nz, k = r - jl * nz;
-      lds[(sl * TJ + jl) * cs + k] = ss[r];
+    for (int u = 0; u < U; u++) { const int r = r0 + u * nt; v[u] = r < run ? src[r] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = r0 + u * nt;
+      if (r < run) { const int jl = p2 ? (r >> lz) : r / nz, k = r - jl * nz; lds[(jl & 1) * H + (jl >> 1) * cs + k] = v[u]; }
     }
   }
   __syncthreads();
-  const long long ob = (long long)i * L.plane;
-#pragma unroll
-  for (int sl = 0; sl < NS; sl++) {
-    double *__restrict__ os = out.s[sl];
-    for (int t = threadIdx.x; t < TJ * nz; t += blockDim.x) {
-      const int jl = t & (TJ - 1), k = t >> 4;
-      if (jl < nj) os[ob + (long long)k * L.RS + jpos(L, j0 + jl)] = lds[(sl * TJ + jl) * cs + k];
-    }
+  double *__restrict__ os = out.s[sl] + (long long)i * L.plane;
+  const int hj = TJ >> 1;  // column pairs per tile; j0 is even (TJ is), so local parity = global parity
+  for (int t = threadIdx.x; t < TJ * nz; t += nt) {
+    const int q = t % hj, par = (t / hj) & 1, k = t / TJ;
+    const int jl = 2 * q + par;
+    if (jl < nj) os[(long long)k * L.RS + (par ? L.HO : L.EO) + ((j0 + jl) >> 1)] = lds[par * H + q * cs + k];
   }
 }
 
@@ -876,22 +877,31 @@ void mgxk_convert(hipStream_t st, const LevView *L, double *js, double *ref, int
   const long long n = (long long)L->nz * (L->ny + 2) * (L->nx + 2);
   hipLaunchKernelGGL(k_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *L, js, ref, nslot, slot, dir);
 }
+// tile width of k_convert_slots: 128 columns while the tile fits the LDS (nz <= 128), else the largest multiple of 16 that does
+static int convert_tile(const LevView *L) {
+  int tj = 128;
+  while (tj > 16 && (size_t)tj * (L->nz + 1) * sizeof(double) > 150 * 1024) tj -= 16;
+  return tj;
+}
+static void convert_slots(hipStream_t st, const LevView *L, const Slots8 &o, int ns, const double *ref) {
+  const int tj = convert_tile(L);
+  const size_t lds = (size_t)tj * (L->nz + 1) * sizeof(double);
+  // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_convert_slots, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(k_convert_slots, dim3((L->ny + 2 + tj - 1) / tj, L->nx + 2, ns), dim3(256), lds, st, *L, o, ref, tj);
+}
 void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {
   Slots8 o;
   for (int q = 0; q < 8; q++) o.s[q] = L->cA[q];
-  const size_t lds = (size_t)8 * 16 * (L->nz + 1) * sizeof(double);
-  // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
-  (void)hipFuncSetAttribute((const void *)k_convert8<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_convert8<8>, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
+  convert_slots(st, L, o, 8, ref);
 }
 // two slot-major arrays (nz, 0:ny+1, 0:nx+1) at ref, ref + n3 -> the JS arrays out0, out1 (the slopes zy, zx)
 void mgxk_convert2(hipStream_t st, const LevView *L, double *out0, double *out1, const double *ref) {
   Slots8 o;
   for (int q = 0; q < 8; q++) o.s[q] = nullptr;
   o.s[0] = out0; o.s[1] = out1;
-  const size_t lds = (size_t)2 * 16 * (L->nz + 1) * sizeof(double);
-  (void)hipFuncSetAttribute((const void *)k_convert8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_convert8<2>, dim3((L->ny + 2 + 15) / 16, L->nx + 2), dim3(256), lds, st, *L, o, ref);
+  convert_slots(st, L, o, 2, ref);
 }
 void mgxk_gather_place(hipStream_t st, const LevView *C, double *dstjs, const double *blk, int nxc, int nyc, int l, int m) {
   const long long n = (long long)C->nz * nyc * nxc;
