@@ -149,6 +149,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the K timed steps are enqueued back to back (option "async": Vcycle returns without waiting for the stream, as a GPU-resident model
+    # calls it) and the region closes with the barrier + synchronize of the contract, after which the library reports device-side errors
+    nhydro.set_option("async", 1)
     for _ in range(args.warmup):
         mg.Vcycle(1)
     sync()
@@ -157,6 +160,8 @@ def main():
         mg.Vcycle(1)
     sync()
     dt = time.perf_counter() - t0
+    nhydro.synchronize()
+    nhydro.set_option("async", 0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

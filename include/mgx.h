@@ -165,6 +165,11 @@ int mgx_set_verbose(int level);
  * With 0 the colour pass is parallel and reads those four values as they were before the pass (the reference's own
  * results differ by 2.5e-6 between decompositions for the same reason; tolerance in DESIGN.md section 2). */
 int mgx_set_option(const char *name, int value);
+/* Option "async" (default 0): the cycle / operator entry points (mgx_vcycle, mgx_vcycle2, mgx_fcycle, mgx_relax, mgx_fine2coarse,
+ * mgx_coarse2fine) only ENQUEUE their kernels on the solver's stream and return -- what a GPU-resident model wants between its own
+ * kernels.  mgx_synchronize() waits for the stream and reports what the device flagged meanwhile (a peer that never showed up, a
+ * rejected launch); every entry point that returns data to the host (mgx_residual, mgx_solve_p, mgx_get_field ...) synchronises anyway. */
+int mgx_synchronize(void);
 /* read back an option, or an integer / logical member of /nhparam/ as mgx_init took it from nh_namelist ("bmask", "nsmall",
  * "solver_maxiter", "ns_coarsest", "ns_pre", "ns_post", "netcdf_output", "aggressive"): the reference's drivers read these module
  * variables of mg_namelist directly (e.g. `if (bmask)`, mg_testseamount.f90) */

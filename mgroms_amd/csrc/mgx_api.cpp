@@ -165,6 +165,7 @@ struct State {
   int use_small = 1;  // one-launch relax on small levels (MGX_NO_SMALL=1 disables, for A/B tests)
   int ksp_test_stall = 0;  // test hook (option "ksp_test_stall" = i): in the next persistent relax the workgroup of plane i returns at once
   int use_fuse = 1;   // option "fuse_tail" / MGX_NO_WAVE_FUSE=1: coarse2fine / residual+restriction folded into the one-workgroup relax of the level below the coarsest (A/B)
+  int async_ops = 0;  // option "async": mgx_vcycle / mgx_fcycle / mgx_relax / mgx_fine2coarse / mgx_coarse2fine return without waiting for the stream
   int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -959,6 +960,10 @@ int sync_stream() {
   return 0;
 }
 
+// end of a cycle / operator entry point: wait for the stream (and report what the device flagged), unless the caller asked for asynchronous
+// operators (option "async"): then the work is only enqueued, as a GPU-resident model would want, and mgx_synchronize reports later
+int op_sync() { return S.async_ops ? 0 : sync_stream(); }
+
 int apply_params(const mgx_params &p) {
   if (streq(p.relax_method, "GS") || streq(p.relax_method, "Gauss-Seidel")) S.method = M_GS;
   else if (streq(p.relax_method, "RB") || streq(p.relax_method, "Red-Black")) S.method = M_RB;
@@ -1209,11 +1214,11 @@ void mgx_clean(void) {
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   if (S.kerr) (void)hipHostFree(S.kerr);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1418,13 +1423,13 @@ int mgx_solve_p(double tol, int maxite, int *nite, double *res, double *hist) {
   if (!S.have_matrix) return fail("no matrix: call mgx_matrices (or mgx_set_field(lev, MGX_CA, ...)) first");
   return solve_p(tol, maxite, nite, res, hist);
 }
-int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); CHK(sync_stream()); return 0; }
-int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); CHK(sync_stream()); return 0; }
-int mgx_vcycle2(int lev1, int lev2) { NEED_LEV(lev1); NEED_LEV(lev2); if (lev2 < lev1) return fail("Vcycle2: lev2 < lev1"); CHK(vcycle2(lev1, lev2)); CHK(sync_stream()); return 0; }
-int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); CHK(sync_stream()); return 0; }
+int mgx_fcycle(void) { NEED_INIT(); CHK(fcycle()); CHK(op_sync()); return 0; }
+int mgx_vcycle(int lev) { NEED_LEV(lev); CHK(vcycle(lev)); CHK(op_sync()); return 0; }
+int mgx_vcycle2(int lev1, int lev2) { NEED_LEV(lev1); NEED_LEV(lev2); if (lev2 < lev1) return fail("Vcycle2: lev2 < lev1"); CHK(vcycle2(lev1, lev2)); CHK(op_sync()); return 0; }
+int mgx_relax(int lev, int nsweeps) { NEED_LEV(lev); CHK(relax(lev, nsweeps)); CHK(op_sync()); return 0; }
 int mgx_residual(int lev, double *res) { NEED_LEV(lev); double r; CHK(residual(lev, &r)); if (res) *res = r; return 0; }
-int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); CHK(sync_stream()); return 0; }
-int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); CHK(sync_stream()); return 0; }
+int mgx_fine2coarse(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("fine2coarse(%d): no coarser level", lev); CHK(fine2coarse(lev)); CHK(op_sync()); return 0; }
+int mgx_coarse2fine(int lev) { NEED_LEV(lev); if (lev >= S.nlevs) return fail("coarse2fine(%d): no coarser level", lev); CHK(coarse2fine(lev)); CHK(op_sync()); return 0; }
 // the generic fill_halo(lev, field) of mg_mpi_exchange.f90:10-16: 3-D solver fields p, b, r (fill_halo_3D[_relax], nh = 1), the 2-D
 // geometry dx, dy, zeta, h (fill_halo_2D), zr / zw (fill_halo_3D with nh = 2: extrapolation at physical sides, :956-964) and the
 // 4-D cA (fill_halo_4D: neighbour exchange only).  Collective over the ranks.
@@ -1502,6 +1507,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "ksp")) S.use_ksp = value;
+  else if (streq(name, "async")) S.async_ops = value;
   else if (streq(name, "fuse_tail")) S.use_fuse = value;
   else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
   else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
@@ -1535,6 +1541,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "ksp")) *value = S.use_ksp;
+  else if (streq(name, "async")) *value = S.async_ops;
   else if (streq(name, "fuse_tail")) *value = S.use_fuse;
   else if (streq(name, "p2p_failed")) *value = S.p2p_failed;
   else if (streq(name, "p2p")) *value = S.p2p_on ? 1 : 0;
@@ -1565,6 +1572,8 @@ int mgx_print_tictoc(const char *path) {
   return 0;
 }
 
+// wait for everything enqueued on the solver's stream and report device-side errors (time-outs, rejected launches); the counterpart of option "async"
+int mgx_synchronize(void) { NEED_INIT(); return sync_stream(); }
 int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }
 int mgx_level_dims(int lev, int *nx, int *ny, int *nz) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *nx = L.nx; *ny = L.ny; *nz = L.nz; return 0; }
 int mgx_level_info(int lev, int *out) {

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
       (void)pc_m; (void)pjm_m; (void)pjp_m; (void)pim_m; (void)pip_m; (void)c3m; (void)c5; (void)c6m; (void)c8; (void)a2_0;
   /* fine2coarse_3D (mg_intergrids.f90:149-160): (k,jA,iA) + (k,jA,iB) + (k,jB,iA) + (k,jB,iB), then the same of k+1;
      the iB values come from the partner lane (lane ^ 32) */
-#define RR_SUM(k)                                                                                                           \
+#define RR_SUM(k, r)                                                                                                        \
     const double rA_B = __shfl_xor(r[0], 32, 64), rB_B = __shfl_xor(r[1], 32, 64);                                          \
     if ((k) & 1) z = r[0] + rA_B + r[1] + rB_B;                                                                             \
     else {                                                                                                                  \
@@ -143,6 +143,21 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
         if (zero) { zero[oc + rc] = 0.0; mirror_store(C, zero, rc, j2, i2, jpos(C, j2), 0.0, ph); }                          \
       }                                                                                                                     \
     }
+  /* interior rows, mg_relax.f90:484-496; diagonal = minus the sum of the fourteen couplings (mg_define_matrix.f90:632-639) */
+#define RR_GENERAL(rr, R0)                                                                                                  \
+      {                                                                                                                     \
+        const double dk = -a2_0 - a2_p - a4o - a4jp - a7o - a7ip - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;               \
+        rr = R0.B[jj] - dk * pc_0 - a2_0 * pc_m - a2_p * pc_p - c3 * pjm_p - c3m * pjp_m                                    \
+                      - a4o * pjm_0 - a4jp * pjp_0 - c5 * pjm_m - c5m * pjp_p                                                \
+                      - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0                                                \
+                      - c8 * pim_m - c8m * pip_p;                                                                            \
+      }
+  /* last row, :498-509 (stored diagonal) */
+#define RR_LAST(rr, R0)                                                                                                     \
+      {                                                                                                                     \
+        rr = R0.B[jj] - dlast[jj] * pc_0 - a2_0 * pc_m - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0                           \
+                      - c5 * pjm_m - c6m * pip_m - a7o * pim_0 - a7ip * pip_0 - c8 * pim_m;                                  \
+      }
 #define RR_STEP(k, Wm, W0, Wp, Wn, R0, Rn)                                                                                  \
   {                                                                                                                         \
     RR_LOADS(k, Wn, Rn)                                                                                                     \
@@ -150,19 +165,11 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
     _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                                     \
       RR_CELL_IN(Wm, W0, Wp, R0)                                                                                            \
       double rr;                                                                                                            \
-      if ((k) < nz) { /* mg_relax.f90:484-496; diagonal = minus the sum of the fourteen couplings (mg_define_matrix.f90:632-639) */ \
-        const double dk = -a2_0 - a2_p - a4o - a4jp - a7o - a7ip - c6 - c6m - c8 - c8m - c3 - c3m - c5 - c5m;               \
-        rr = R0.B[jj] - dk * pc_0 - a2_0 * pc_m - a2_p * pc_p - c3 * pjm_p - c3m * pjp_m                                    \
-                      - a4o * pjm_0 - a4jp * pjp_0 - c5 * pjm_m - c5m * pjp_p                                                \
-                      - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0                                                \
-                      - c8 * pim_m - c8m * pip_p;                                                                            \
-      } else { /* :498-509 */                                                                                               \
-        rr = R0.B[jj] - dlast[jj] * pc_0 - a2_0 * pc_m - c3m * pjp_m - a4o * pjm_0 - a4jp * pjp_0                           \
-                      - c5 * pjm_m - c6m * pip_m - a7o * pim_0 - a7ip * pip_0 - c8 * pim_m;                                  \
-      }                                                                                                                     \
+      if ((k) < nz) RR_GENERAL(rr, R0)                                                                                       \
+      else RR_LAST(rr, R0)                                                                                                  \
       r[jj] = rr;                                                                                                           \
     }                                                                                                                       \
-    RR_SUM(k)                                                                                                               \
+    RR_SUM(k, r)                                                                                                            \
   }
   {  // k = 1 (mg_relax.f90:464-482), peeled: its stored diagonal, the k = 1 diagonal slots and the four corner values of p
      // (horizontal diagonals of cmatrix = 'real', :475-479) live only here
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
       if (REAL) rr = rr - a5[g.o + c] * F.p[g.om + jp] - a5[g.op + jm] * F.p[g.op + jm] - a8[g.o + c] * F.p[g.om + jm] - a8[g.op + jp] * F.p[g.op + jp];
       r[jj] = rr;
     }
-    RR_SUM(1)
+    RR_SUM(1, r)
   }
   for (int k = 2; k <= nz; k += 4) {
     RR_STEP(k, WB, WC, WD, WA, RB, RA)
@@ -186,10 +193,90 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
     if (k + 3 <= nz) RR_STEP(k + 3, WA, WB, WC, WD, RA, RB)
   }
 #undef RR_STEP
-#undef RR_SUM
-#undef RR_CELL_IN
 #undef RR_LOADS
 }
+
+// The same operator without the walk.  A lane that climbs its column pays one memory round trip per row step (20 us for nz = 16 and 13 us
+// for nz = 8 on 8-32 CUs, measured), but nothing in r = b - A p is sequential in k.  Here one wave owns S fine rows (S/2 coarse rows) of 32
+// coarse columns (both fine planes, as above): the S + 2 window rows and the S rows' own values are all requested at once, the rows are
+// computed and the 8-cell sums closed with the partner lane -- one round trip, nz/S times the waves.  Same expressions (the macros above),
+// same order: bit-identical.
+template <bool REAL, int S>
+__global__ __launch_bounds__(64) void k_residual_restrict_flat(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx) {
+  // 1-D grid, k fastest: the nz/S waves of one (plane, j-chunk) share two of their window rows with the wave above and below, so they
+  // are kept together in time and on ONE XCD (workgroups are dealt to the eight XCDs round-robin), where that re-use is an L2 hit
+  const int nz = F.nz, nks = (nz + S - 1) / S, ng = gx * C.nx;
+  int grp, ks;
+  if ((ng & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; ks = local % nks; grp = xcd * (ng >> 3) + local / nks; }
+  else { ks = blockIdx.x % nks; grp = blockIdx.x / nks; }
+  const int i2 = 1 + grp / gx, bx = grp - (grp / gx) * gx;
+  const int half = threadIdx.x >> 5;
+  int j2 = 1 + bx * 32 + (threadIdx.x & 31);
+  const bool live = j2 <= C.ny;
+  if (!live) j2 = C.ny;
+  const int k = ks * S + 1;  // fine rows k (odd) .. k + S - 1 (those <= nz; nz is even)
+  const long long RS = F.RS;
+  Geo g;
+  g.o = (long long)(2 * i2 - 1 + half) * F.plane; g.om = g.o - F.plane; g.op = g.o + F.plane;
+  g.c[1] = F.HO + (j2 - 1); g.c[2] = F.EO + j2; g.c[0] = F.EO + (j2 - 1); g.c[3] = F.HO + j2;
+  const double qrt = 0.25;
+  const double *__restrict__ a1 = F.cA[0], *__restrict__ a5 = F.cA[4], *__restrict__ a8 = F.cA[7];
+  RowW W[S + 2];  // rows k-1 .. k+S, clamped to 1 .. nz (the clamped copies are never used: the first and the last row have their own expressions)
+  RowR R[S];
+#pragma unroll
+  for (int r = 0; r < S + 2; r++) {
+    const int kr = k - 1 + r < 1 ? 1 : (k - 1 + r > nz ? nz : k - 1 + r);
+    load_w(W[r], F, g, (long long)(kr - 1) * RS);
+  }
+#pragma unroll
+  for (int r = 0; r < S; r++) {
+    const int kr = k + r > nz ? nz : k + r;
+    load_r(R[r], F, g, (long long)(kr - 1) * RS);
+  }
+  double dedge[2] = {0.0, 0.0}, e[2][8];
+  if (k == 1) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+      const int c = g.c[jj + 1], jm = g.c[jj], jp = g.c[jj + 2];
+      dedge[jj] = a1[g.o + c];
+      if (REAL) {
+        e[jj][0] = a5[g.o + c]; e[jj][1] = F.p[g.om + jp]; e[jj][2] = a5[g.op + jm]; e[jj][3] = F.p[g.op + jm];
+        e[jj][4] = a8[g.o + c]; e[jj][5] = F.p[g.om + jm]; e[jj][6] = a8[g.op + jp]; e[jj][7] = F.p[g.op + jp];
+      }
+    }
+  }
+  double dlast[2] = {0.0, 0.0};
+  if (k + S > nz) {
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) dlast[jj] = a1[g.o + (long long)(nz - 1) * RS + g.c[jj + 1]];
+  }
+  double z = 0.0;
+  const long long oc = (long long)i2 * C.plane + jpos(C, j2);
+#pragma unroll
+  for (int r = 0; r < S; r++) {
+    const int kr = k + r;
+    if (kr <= nz) {  // wave-uniform
+      double rv[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+        RR_CELL_IN(W[r], W[r + 1], W[r + 2], R[r])
+        double rr;
+        if (r == 0 && kr == 1) {
+          rr = R[r].B[jj] - dedge[jj] * pc_0 - a2_p * pc_p - c3 * pjm_p - a4o * pjm_0 - a4jp * pjp_0
+                          - c5m * pjp_p - c6 * pim_p - a7o * pim_0 - a7ip * pip_0 - c8m * pip_p;
+          if (REAL) rr = rr - e[jj][0] * e[jj][1] - e[jj][2] * e[jj][3] - e[jj][4] * e[jj][5] - e[jj][6] * e[jj][7];
+        } else if (kr < nz) RR_GENERAL(rr, R[r])
+        else RR_LAST(rr, R[r])
+        rv[jj] = rr;
+      }
+      RR_SUM(kr, rv)  /* odd row: z = its four values; even row: z += its four values, store coarse row kr/2 */
+    }
+  }
+}
+#undef RR_SUM
+#undef RR_CELL_IN
+#undef RR_GENERAL
+#undef RR_LAST
 
 extern "C" {
 
@@ -200,6 +287,17 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
   if (off || F->zy == nullptr || F->nz < 2 || (F->nz & 1)) return 0;
   if (C->nx * 2 != F->nx || C->ny * 2 != F->ny) return 0;
   if ((long long)F->nx * F->ny * F->nz < mincells) return 0;
+  static const long long flatmax = getenv("MGX_RESREST_FLAT_MAX") ? atoll(getenv("MGX_RESREST_FLAT_MAX")) : 256LL * 256 * 32;
+  if ((long long)F->nx * F->ny * F->nz <= flatmax) {  // no walk: one wave per S fine rows, one round trip
+    static const int senv = getenv("MGX_RESREST_FLAT_S") ? atoi(getenv("MGX_RESREST_FLAT_S")) : 0;
+    const int gx = (C->ny + 31) / 32, Sr = senv ? senv : 2;
+    dim3 blk(WAVE);
+#define RRF(REALV, SV) hipLaunchKernelGGL((k_residual_restrict_flat<REALV, SV>), dim3((unsigned)gx * C->nx * ((F->nz + SV - 1) / SV)), blk, 0, st, *F, *C, dst, ph, zero, gx)
+    if (Sr >= 4 && F->nz >= 4) { if (real) RRF(true, 4); else RRF(false, 4); }
+    else { if (real) RRF(true, 2); else RRF(false, 2); }
+#undef RRF
+    return mgx_launched();
+  }
   const int by = 4, gx = (C->ny + 31) / 32, gy = (C->nx + by - 1) / by;
   dim3 blk(WAVE, by), grd(gx * gy);
   if (real) hipLaunchKernelGGL((k_residual_restrict<true>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy);

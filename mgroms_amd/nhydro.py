@@ -57,6 +57,11 @@ def set_option(name, value):
     check(lib().mgx_set_option(name.encode(), int(value)))
 
 
+def synchronize():
+    """wait for the solver's stream and raise what the device flagged (counterpart of set_option("async", 1))"""
+    check(lib().mgx_synchronize())
+
+
 def get_option(name):
     """read back an option or an integer / logical member of /nhparam/ (include/mgx.h: mgx_get_option)"""
     v = C.c_int()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel time of the solve_p iterations in a rocprofv3 --kernel-trace CSV (the last `nit` iterations = everything after the last
-k_sumsq), and the idle gaps between consecutive kernels.  python3 scripts/solve_breakdown.py <kernel_trace.csv> <nit>"""
+k_sumsq), and the idle gaps between consecutive kernels.  python3 scripts/solve_breakdown.py <kernel_trace.csv> <nit> [bygrid]
+(bygrid: one line per kernel AND launch size, which separates the levels of the hierarchy)"""
 import csv
 import sys
 from collections import defaultdict
@@ -16,6 +17,8 @@ for a, b in zip(rows, rows[1:]):
     gap += max(0, int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    if len(sys.argv) > 3:
+        n = "%s  grid %sx%sx%s" % (n[:60], r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?"))
     tot[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     cnt[n] += 1
 span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])

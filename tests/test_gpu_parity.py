@@ -498,6 +498,28 @@ def test_c2f_skip_is_invisible(mg, dims):
     assert np.array_equal(out[0][2], out[1][2])
 
 
+def test_async_operators_same_bits(mg):
+    """Option "async": the cycle entry points only enqueue and mgx_synchronize waits and reports.  Three V-cycles enqueued back to
+    back leave the same bits as three synchronous ones, and entry points that return data to the host wait by themselves."""
+    nx, ny, nz = 48, 32, 16
+    out = []
+    for a in (0, 1):
+        mg.nhydro.set_option("async", a)
+        try:
+            _setup(mg, nx, ny, nz)
+            mg.nhydro.compute_rhs(*_uvw(nx, ny, nz, seed=9))
+            for _ in range(3):
+                mg.Vcycle(1)
+            if a:
+                assert mg.nhydro.get_option("async") == 1
+                mg.nhydro.synchronize()
+            out.append([mg.grid(l).p for l in range(1, mg.nlevs() + 1)])
+        finally:
+            mg.nhydro.set_option("async", 0)
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_fortran_harness_bmask(mg, tmp_path):
     """bmask = .true. through the Fortran boundary: the driver masks the boundary ring of rmask as the reference's does
     (fill_halo_2D_bmask(1,rmask) before nhydro_matrices, mg_testseamount.f90 / mg_mpi_exchange.f90:357-391; `bmask` read from the
