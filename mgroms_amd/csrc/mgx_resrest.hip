@@ -79,7 +79,7 @@ __device__ __forceinline__ void load_r(RowR &r, const LevView &F, const Geo &g, 
 // grid: 1-D, gx j-chunks of 32 coarse columns x gy groups of blockDim.y coarse planes, XCD-aware as k_relax_nz.
 // One wave per SIMD (360 registers: four window rows + two row buffers, so that the next rows load while one is computed;
 // squeezed to 256 registers for two waves per SIMD it spills and loses: 250 vs 236 us at 512x512x64, 45 vs 78 at 256x256x32).
-template <bool REAL>
+template <bool REAL, int AW, int AR>
 __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx, int gy) {
   int bx, by;
   if ((gy & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; by = xcd * (gy >> 3) + local / gx; bx = local - (local / gx) * gx; }
@@ -102,19 +102,41 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
   double dlast[2];
 #pragma unroll
   for (int jj = 0; jj < 2; jj++) dlast[jj] = a1[g.o + (long long)(nz - 1) * RS + g.c[jj + 1]];
-  RowW WA, WB, WC, WD;
-  RowR RA, RB;
-  load_w(WB, F, g, 0);
-  load_w(WC, F, g, RS);
-  load_r(RA, F, g, 0);
+  // first row: stored diagonal, the k = 1 diagonal slots and the four corner values of p (horizontal diagonals of cmatrix = 'real',
+  // mg_relax.f90:475-479) -- requested before the rows, so that the first step does not wait for the look-ahead behind them
+  double dedge[2], e[2][8];
+#pragma unroll
+  for (int jj = 0; jj < 2; jj++) {
+    const int c = g.c[jj + 1], jm = g.c[jj], jp = g.c[jj + 2];
+    dedge[jj] = a1[g.o + c];
+    if (REAL) {
+      e[jj][0] = a5[g.o + c]; e[jj][1] = F.p[g.om + jp]; e[jj][2] = a5[g.op + jm]; e[jj][3] = F.p[g.op + jm];
+      e[jj][4] = a8[g.o + c]; e[jj][5] = F.p[g.om + jm]; e[jj][6] = a8[g.op + jp]; e[jj][7] = F.p[g.op + jp];
+    }
+  }
+  // Look-ahead: the window rows are requested AW steps and the rows' own values AR steps before their first use.  With AW = AR = 1 (one
+  // wave per SIMD, ~45 requests in flight) a step cost a whole memory round trip: 4300 cycles per row at 512x512x64.
+  constexpr int NWB = 3 + AW, NRB = 1 + AR;  // buffers: rows k-1, k, k+1 + AW ahead; row k + AR ahead
+  constexpr int U = (NWB % NRB == 0) ? NWB : NWB * NRB;  // steps after which both rotations are back where they started
+  static_assert(U <= 12, "unroll");
+  RowW W[NWB];
+  RowR R[NRB];
+  // before the peeled k = 1 step: W[0 .. AW+1] = rows 1 .. AW+2, R[NRB-1] = row 1, R[0 .. AR-2] = rows 2 .. AR.
+  // Every request is UNCONDITIONAL (rows past the top are clamped to nz and never used): a request inside a branch makes the number of
+  // outstanding loads path-dependent, the compiler then waits for vmcnt(0) at every step and the look-ahead is void (measured: one memory
+  // round trip per row, whatever AW / AR).
+#pragma unroll
+  for (int q = 0; q < AW + 2; q++) load_w(W[q], F, g, (long long)(q + 1 <= nz ? q : nz - 1) * RS);
+  load_r(R[NRB - 1], F, g, 0);
+#pragma unroll
+  for (int q = 0; q < AR - 1; q++) load_r(R[q], F, g, (long long)(q + 2 <= nz ? q + 1 : nz - 1) * RS);
   double z = 0.0;
   const long long oc = (long long)i2 * C.plane + jpos(C, j2);
 
-  // one fine row: Wm / W0 / Wp hold rows k-1, k, k+1; Wn receives row k+2 and Rn row k+1 while row k is computed
+  // one fine row k: Wm / W0 / Wp hold rows k-1, k, k+1; Wn receives row k+1+AW and Rn row k+AR while row k is computed
 #define RR_LOADS(k, Wn, Rn)                                                                                                 \
-    const long long ro = (long long)((k)-1) * RS;                                                                            \
-    if ((k) + 2 <= nz) load_w(Wn, F, g, ro + 2 * RS);                                                                        \
-    if ((k) + 1 <= nz) load_r(Rn, F, g, ro + RS);
+    load_w(Wn, F, g, (long long)((k) + 1 + AW <= nz ? (k) + AW : nz - 1) * RS);                                              \
+    load_r(Rn, F, g, (long long)((k) + AR <= nz ? (k) + AR - 1 : nz - 1) * RS);
 #define RR_CELL_IN(Wm, W0, Wp, R0)                                                                                          \
       const double pc_m = Wm.P[jj + 1], pc_0 = W0.P[jj + 1], pc_p = Wp.P[jj + 1];                                            \
       const double pjm_m = Wm.P[jj], pjm_0 = W0.P[jj], pjm_p = Wp.P[jj];                                                     \
@@ -171,26 +193,29 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
     }                                                                                                                       \
     RR_SUM(k, r)                                                                                                            \
   }
-  {  // k = 1 (mg_relax.f90:464-482), peeled: its stored diagonal, the k = 1 diagonal slots and the four corner values of p
-     // (horizontal diagonals of cmatrix = 'real', :475-479) live only here
-    RR_LOADS(1, WD, RB)
+  {  // k = 1 (mg_relax.f90:464-482), peeled
+    RR_LOADS(1, W[AW + 2], R[AR - 1])
     double r[2];
 #pragma unroll
     for (int jj = 0; jj < 2; jj++) {
-      RR_CELL_IN(WB, WB, WC, RA)
-      const int c = g.c[jj + 1], jm = g.c[jj], jp = g.c[jj + 2];
-      double rr = RA.B[jj] - a1[g.o + c] * pc_0 - a2_p * pc_p - c3 * pjm_p - a4o * pjm_0 - a4jp * pjp_0
-                           - c5m * pjp_p - c6 * pim_p - a7o * pim_0 - a7ip * pip_0 - c8m * pip_p;
-      if (REAL) rr = rr - a5[g.o + c] * F.p[g.om + jp] - a5[g.op + jm] * F.p[g.op + jm] - a8[g.o + c] * F.p[g.om + jm] - a8[g.op + jp] * F.p[g.op + jp];
+      RR_CELL_IN(W[0], W[0], W[1], R[NRB - 1])
+      double rr = R[NRB - 1].B[jj] - dedge[jj] * pc_0 - a2_p * pc_p - c3 * pjm_p - a4o * pjm_0 - a4jp * pjp_0
+                                   - c5m * pjp_p - c6 * pim_p - a7o * pim_0 - a7ip * pip_0 - c8m * pip_p;
+      if (REAL) rr = rr - e[jj][0] * e[jj][1] - e[jj][2] * e[jj][3] - e[jj][4] * e[jj][5] - e[jj][6] * e[jj][7];
       r[jj] = rr;
     }
     RR_SUM(1, r)
   }
-  for (int k = 2; k <= nz; k += 4) {
-    RR_STEP(k, WB, WC, WD, WA, RB, RA)
-    if (k + 1 <= nz) RR_STEP(k + 1, WC, WD, WA, WB, RA, RB)
-    if (k + 2 <= nz) RR_STEP(k + 2, WD, WA, WB, WC, RB, RA)
-    if (k + 3 <= nz) RR_STEP(k + 3, WA, WB, WC, WD, RA, RB)
+  // rows 2 .. nz, U steps per trip: at step q of a trip rows k-1, k, k+1 sit in W[q], W[q+1], W[q+2] (mod NWB) and row k's own values in
+  // R[q mod NRB].  Whole trips run without a branch around a step; the last nz - 1 mod U rows follow, guarded (the rotation is back at 0).
+  int k = 2;
+  for (; k + U - 1 <= nz; k += U) {
+#pragma unroll
+    for (int q = 0; q < U; q++) RR_STEP(k + q, W[q % NWB], W[(q + 1) % NWB], W[(q + 2) % NWB], W[(q + 2 + AW) % NWB], R[q % NRB], R[(q + AR) % NRB])
+  }
+#pragma unroll
+  for (int q = 0; q < U - 1; q++) {
+    if (k + q <= nz) RR_STEP(k + q, W[q % NWB], W[(q + 1) % NWB], W[(q + 2) % NWB], W[(q + 2 + AW) % NWB], R[q % NRB], R[(q + AR) % NRB])
   }
 #undef RR_STEP
 #undef RR_LOADS
@@ -300,8 +325,16 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
   }
   const int by = 4, gx = (C->ny + 31) / 32, gy = (C->nx + by - 1) / by;
   dim3 blk(WAVE, by), grd(gx * gy);
-  if (real) hipLaunchKernelGGL((k_residual_restrict<true>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy);
-  else hipLaunchKernelGGL((k_residual_restrict<false>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy);
+  static const int deep = getenv("MGX_RESREST_AHEAD") ? atoi(getenv("MGX_RESREST_AHEAD")) : 11;  // 10 * AW + AR (A/B: scripts/probe/ab_resrest_ahead.sh -- 11, 12, 21 within 5 % of each other once the requests are unconditional)
+#define RRW(REALV, AWV, ARV) hipLaunchKernelGGL((k_residual_restrict<REALV, AWV, ARV>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy)
+#define RRW2(AWV, ARV) { if (real) RRW(true, AWV, ARV); else RRW(false, AWV, ARV); }
+  switch (deep) {
+    case 12: RRW2(1, 2) break;
+    case 21: RRW2(2, 1) break;
+    default: RRW2(1, 1) break;
+  }
+#undef RRW2
+#undef RRW
   return mgx_launched();
 }
 

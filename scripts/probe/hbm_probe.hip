@@ -77,6 +77,50 @@ __global__ __launch_bounds__(256) void k_stencil(const double *__restrict__ base
   if (acc == 123.456) out[0] = acc;
 }
 
+// 5. the walk of (3) at the occupancy of the solver's register-heavy kernels: one wave per SIMD (a block of 64 lanes that asks for 40 KB of LDS:
+//    four blocks per CU), NA arrays x U rows requested before the first use
+template <int NA, int U>
+__global__ __launch_bounds__(64) void k_walk_1w(const double *__restrict__ base, size_t arr, int RS, int nz, size_t plane, double *out) {
+  extern __shared__ double pad[];
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
+  const double *p = base + (size_t)i * plane + j;
+  double acc = 0.0;
+  for (int k = 0; k < nz; k += U) {
+    double v[NA][U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int q = 0; q < NA; q++) v[q][u] = p[(size_t)q * arr + (size_t)(k + u) * RS];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int q = 0; q < NA; q++) acc += v[q][u];
+  }
+  if (acc == 123.456) { out[0] = acc; pad[threadIdx.x] = acc; }
+}
+
+// 6. the same with the wave split over TWO planes (lanes 0-31 plane i, lanes 32-63 plane i+1: 256-byte segments), as the fused
+//    residual+restriction kernel is laid out
+template <int NA, int U>
+__global__ __launch_bounds__(64) void k_walk_split(const double *__restrict__ base, size_t arr, int RS, int nz, size_t plane, double *out) {
+  extern __shared__ double pad[];
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31), i = blockIdx.y * 2 + (threadIdx.x >> 5);
+  const double *p = base + (size_t)i * plane + j;
+  double acc = 0.0;
+  for (int k = 0; k < nz; k += U) {
+    double v[NA][U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int q = 0; q < NA; q++) v[q][u] = p[(size_t)q * arr + (size_t)(k + u) * RS];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int q = 0; q < NA; q++) acc += v[q][u];
+  }
+  if (acc == 123.456) { out[0] = acc; pad[threadIdx.x] = acc; }
+}
+
 template <class F> float timeit(F f, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
@@ -114,5 +158,11 @@ int main() {
     printf("stencil walk %d arrays x %d requests per cell (%s): %7.1f us  %6.2f TB/s of new data, %5.1f instr/cell, %5.1f cycles per instruction and CU\n", NA, DUP, WIDE ? "16 B" : " 8 B", \
            ms * 1e3, useful8 / ms, (double)NA * DUP / (WIDE ? 2 : 1), ms * 1e-3 * 2.4e9 / ((double)nx * ny * nz / 64 / 256 * NA * DUP / (WIDE ? 2 : 1))); }
   STEN(8, 1, false) STEN(8, 2, false) STEN(8, 4, false) STEN(8, 2, true) STEN(8, 4, true) STEN(8, 8, true)
+#define W1(NA, U) { float ms = timeit([&] { hipLaunchKernelGGL((k_walk_1w<NA, U>), dim3(ny / 64, nx), dim3(64), 40 * 1024, 0, a, arr, RS, nz, plane, out); }, 10); \
+    printf("column walk, ONE wave per SIMD, %d arrays x %d rows in flight (%3d requests): %7.1f us  %6.2f TB/s\n", NA, U, NA * U, ms * 1e3, useful8 / ms); }
+  W1(8, 1) W1(8, 2) W1(8, 4) W1(8, 8)
+#define WS(NA, U) { float ms = timeit([&] { hipLaunchKernelGGL((k_walk_split<NA, U>), dim3(ny / 32, nx / 2), dim3(64), 40 * 1024, 0, a, arr, RS, nz, plane, out); }, 10); \
+    printf("column walk, one wave per SIMD, wave split over two planes, %d arrays x %d rows in flight: %7.1f us  %6.2f TB/s\n", NA, U, ms * 1e3, useful8 / ms); }
+  WS(8, 1) WS(8, 2) WS(8, 4)
   return 0;
 }
