@@ -136,27 +136,37 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
                  *__restrict__ a7 = L.cA[6], *__restrict__ a8 = L.cA[7], *__restrict__ zy = L.zy, *__restrict__ zx = L.zx;
     const long long o = (long long)i * L.plane, om = o - L.plane, op = o + L.plane;
     const double qrt = 0.25;
-    double pc_m = 0, pc_0, pc_p, pjm_m = 0, pjm_0, pjm_p, pim_m = 0, pim_0, pim_p, pjp_m = 0, pjp_0, pjp_p, pip_m = 0, pip_0, pip_p;
-    double zy_m = 0, zy_0, zy_p, zx_m = 0, zx_0, zx_p, a2_0, a2_p;
+    // Every request is unconditional (rows past the top clamped to nz, never used) and issued ONE STEP before its first use: the window row
+    // k+2 and the own-row values of k+1 are in flight while row k is computed.  (A request inside `if (k + 2 <= nz)` made the number of
+    // outstanding loads path-dependent: the compiler then waits for vmcnt(0) at every step and the look-ahead is void.)
+    double pc_m = 0, pc_0, pc_p, pc_n, pjm_m = 0, pjm_0, pjm_p, pjm_n, pim_m = 0, pim_0, pim_p, pim_n, pjp_m = 0, pjp_0, pjp_p, pjp_n, pip_m = 0, pip_0, pip_p, pip_n;
+    double zy_m = 0, zy_0, zy_p, zy_n, zx_m = 0, zx_0, zx_p, zx_n, a2_0, a2_p, a2_n;
+    double zyjm, zyjp, zxim, zxip, a4o, a4jp, a7o, a7ip, bk, zyjm_n, zyjp_n, zxim_n, zxip_n, a4o_n, a4jp_n, a7o_n, a7ip_n, bk_n;
 #define LOAD_WIN(q, PC, PJM, PIM, PJP, PIP, ZY, ZX, A2)                        \
-  { const long long ro = (long long)((q)-1) * RS;                              \
+  { const long long ro = (long long)(((q) <= nz ? (q) : nz) - 1) * RS;         \
     PC = p[o + ro + c]; LD_PAIR(p + o + ro + jm, PJM, PJP) PIM = p[om + ro + c]; PIP = p[op + ro + c]; \
     ZY = *(zy + o + ro + c); ZX = *(zx + o + ro + c); A2 = ld_rt(a2 + o + ro + c, stream); }
+#define LOAD_ROWV(q, ZYJM, ZYJP, ZXIM, ZXIP, A4O, A4JP, A7O, A7IP, BK)         \
+  { const long long ro = (long long)(((q) <= nz ? (q) : nz) - 1) * RS, ko = o + ro + c; \
+    LD_PAIR(zy + o + ro + jm, ZYJM, ZYJP) ZXIM = zx[om + ro + c]; ZXIP = zx[op + ro + c]; \
+    A4O = *(a4 + ko); A4JP = a4[o + ro + jp]; A7O = *(a7 + ko); A7IP = a7[op + ro + c]; BK = ld_rt(b + ko, stream); }
+    // rows 1 and nz: stored diagonal; row 1: the k = 1 diagonal slots and the four corner values of p (cmatrix = 'real', mg_relax.f90:475-479)
+    const double d_first = a1[o + c], d_last = a1[o + (long long)(nz - 1) * RS + c];
+    double e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0, e7 = 0;
+    if (REAL) { e0 = a5[o + c]; e1 = p[om + jp]; e2 = a5[op + jm]; e3 = p[op + jm]; e4 = a8[o + c]; e5 = p[om + jm]; e6 = a8[op + jp]; e7 = p[op + jp]; }
     LOAD_WIN(1, pc_0, pjm_0, pim_0, pjp_0, pip_0, zy_0, zx_0, a2_0)
+    LOAD_ROWV(1, zyjm, zyjp, zxim, zxip, a4o, a4jp, a7o, a7ip, bk)
     LOAD_WIN(2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
     for (int k = 1; k <= nz; k++) {
       const long long ro = (long long)(k - 1) * RS, ko = o + ro + c;
-      double zyjm, zyjp;
-      LD_PAIR(zy + o + ro + jm, zyjm, zyjp)
-      const double zxim = zx[om + ro + c], zxip = zx[op + ro + c];
-      const double a4o = *(a4 + ko), a4jp = a4[o + ro + jp], a7o = *(a7 + ko), a7ip = a7[op + ro + c], bk = ld_rt(b + ko, stream);
+      LOAD_WIN(k + 2, pc_n, pjm_n, pim_n, pjp_n, pip_n, zy_n, zx_n, a2_n)
+      LOAD_ROWV(k + 1, zyjm_n, zyjp_n, zxim_n, zxip_n, a4o_n, a4jp_n, a7o_n, a7ip_n, bk_n)
       double rr;
       if (k == 1) {
-        rr = bk - *(a1 + ko) * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - a4o * pjm_0 - a4jp * pjp_0
+        rr = bk - d_first * pc_0 - a2_p * pc_p - (qrt * (zy_p + zyjm)) * pjm_p - a4o * pjm_0 - a4jp * pjp_0
                    - (-qrt * (zyjp + zy_p)) * pjp_p - (qrt * (zx_p + zxim)) * pim_p - a7o * pim_0 - a7ip * pip_0
                    - (-qrt * (zxip + zx_p)) * pip_p;
-        if (REAL)
-          rr = rr - a5[o + c] * p[om + jp] - a5[op + jm] * p[op + jm] - a8[o + c] * p[om + jm] - a8[op + jp] * p[op + jp];
+        if (REAL) rr = rr - e0 * e1 - e2 * e3 - e4 * e5 - e6 * e7;
       } else if (k < nz) {
         const double c3 = qrt * (zy_p + zyjm), c3m = qrt * (zyjp + zy_m), c5 = -qrt * (zy_m + zyjm), c5m = -qrt * (zyjp + zy_p);
         const double c6 = qrt * (zx_p + zxim), c6m = qrt * (zxip + zx_m), c8 = -qrt * (zx_m + zxim), c8m = -qrt * (zxip + zx_p);
@@ -166,18 +176,19 @@ __global__ __launch_bounds__(256) void k_residual_mf(LevView L, double *__restri
                    - c6 * pim_p - c6m * pip_m - a7o * pim_0 - a7ip * pip_0
                    - c8 * pim_m - c8m * pip_p;
       } else {
-        rr = bk - *(a1 + ko) * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - a4o * pjm_0 - a4jp * pjp_0
+        rr = bk - d_last * pc_0 - a2_0 * pc_m - (qrt * (zyjp + zy_m)) * pjp_m - a4o * pjm_0 - a4jp * pjp_0
                    - (-qrt * (zy_m + zyjm)) * pjm_m - (qrt * (zxip + zx_m)) * pip_m - a7o * pim_0 - a7ip * pip_0
                    - (-qrt * (zx_m + zxim)) * pim_m;
       }
       st_rt(r + ko, rr, stream);
       mirror_store(L, r, ro, jodd ? 2 * jh + 1 : 2 * jh + 2, i, c, rr, ph);
       acc = acc + rr * rr;
-      pc_m = pc_0; pc_0 = pc_p; pjm_m = pjm_0; pjm_0 = pjm_p; pim_m = pim_0; pim_0 = pim_p;
-      pjp_m = pjp_0; pjp_0 = pjp_p; pip_m = pip_0; pip_0 = pip_p;
-      zy_m = zy_0; zy_0 = zy_p; zx_m = zx_0; zx_0 = zx_p; a2_0 = a2_p;
-      if (k + 2 <= nz) LOAD_WIN(k + 2, pc_p, pjm_p, pim_p, pjp_p, pip_p, zy_p, zx_p, a2_p)
+      pc_m = pc_0; pc_0 = pc_p; pc_p = pc_n; pjm_m = pjm_0; pjm_0 = pjm_p; pjm_p = pjm_n; pim_m = pim_0; pim_0 = pim_p; pim_p = pim_n;
+      pjp_m = pjp_0; pjp_0 = pjp_p; pjp_p = pjp_n; pip_m = pip_0; pip_0 = pip_p; pip_p = pip_n;
+      zy_m = zy_0; zy_0 = zy_p; zy_p = zy_n; zx_m = zx_0; zx_0 = zx_p; zx_p = zx_n; a2_0 = a2_p; a2_p = a2_n;
+      zyjm = zyjm_n; zyjp = zyjp_n; zxim = zxim_n; zxip = zxip_n; a4o = a4o_n; a4jp = a4jp_n; a7o = a7o_n; a7ip = a7ip_n; bk = bk_n;
     }
+#undef LOAD_ROWV
 #undef LOAD_WIN
   }
   if (!want_norm) return;
@@ -258,16 +269,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
 // `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph, int stream, double *__restrict__ dup, double *__restrict__ zero) {
+// blockIdx.z: a run of KC coarse levels -- nothing here is sequential in k, and one wave per coarse column-chunk (1024 waves at 512x512x64:
+// one per SIMD, a memory round trip per level, 41 us) is a latency chain, not a stream.
+__global__ __launch_bounds__(256) void k_fine2coarse(LevView F, LevView C, double *__restrict__ dst, Sides ph, int stream, double *__restrict__ dup, double *__restrict__ zero, int KC) {
   const int j2 = 1 + blockIdx.x * WAVE + threadIdx.x;
   const int i2 = 1 + blockIdx.y * blockDim.y + threadIdx.y;
   if (j2 > C.ny || i2 > C.nx) return;
+  const int ka = 1 + blockIdx.z * KC, kb = ka + KC - 1 < C.nz ? ka + KC - 1 : C.nz;
   const int i = 2 * i2 - 1;
   const int po = F.HO + (j2 - 1), pe = F.EO + j2;  // fine j = 2*j2-1 (odd) and 2*j2 (even)
   const double *__restrict__ x = F.r;
   const long long o0 = (long long)i * F.plane, o1 = o0 + F.plane;
   const long long oc = (long long)i2 * C.plane + jpos(C, j2);
-  for (int k2 = 1; k2 <= C.nz; k2++) {
+  for (int k2 = ka; k2 <= kb; k2++) {
     const long long r0 = (long long)(2 * k2 - 2) * F.RS, r1 = r0 + F.RS;
     const double z = ld_rt(x + o0 + r0 + po, stream) + ld_rt(x + o1 + r0 + po, stream) + ld_rt(x + o0 + r0 + pe, stream) + ld_rt(x + o1 + r0 + pe, stream)
                    + ld_rt(x + o0 + r1 + po, stream) + ld_rt(x + o1 + r1 + po, stream) + ld_rt(x + o0 + r1 + pe, stream) + ld_rt(x + o1 + r1 + pe, stream);
@@ -377,23 +391,35 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
   // one coarse level: v[3*a + b], a = plane (i2-1, i2, i2+1), b = column (j2-1, j2, j2+1)
 #define ROW(kk, v)                                                                                                  \
   {                                                                                                                 \
-    const long long ro_ = (long long)((kk)-1) * C.RS;                                                               \
+    const long long ro_ = (long long)(((kk) < 1 ? 1 : ((kk) > nz ? nz : (kk))) - 1) * C.RS;                          \
     const double t0_ = xc[qm + ro_ + c0], t1_ = xc[q0 + ro_ + c0], t2_ = xc[qp + ro_ + c0];                         \
     v[1] = t0_; v[4] = t1_; v[7] = t2_;                                                                             \
     v[0] = __shfl_up(t0_, 1, WAVE); v[3] = __shfl_up(t1_, 1, WAVE); v[6] = __shfl_up(t2_, 1, WAVE);                 \
     v[2] = __shfl_down(t0_, 1, WAVE); v[5] = __shfl_down(t1_, 1, WAVE); v[8] = __shfl_down(t2_, 1, WAVE);           \
-    if (lane == 0) { v[0] = xc[qm + ro_ + cm]; v[3] = xc[q0 + ro_ + cm]; v[6] = xc[qp + ro_ + cm]; }                \
-    if (lane == WAVE - 1) { v[2] = xc[qm + ro_ + cp]; v[5] = xc[q0 + ro_ + cp]; v[8] = xc[qp + ro_ + cp]; }         \
+    /* the wave's two outer columns: ONE request per plane, in which lane 0 asks for its j2-1, the last lane for its j2+1 (the others */ \
+    /* repeat their own column) -- selected, not branched to */                                                      \
+    const double e0_ = xc[qm + ro_ + ce], e1_ = xc[q0 + ro_ + ce], e2_ = xc[qp + ro_ + ce];                         \
+    if (lane == 0) { v[0] = e0_; v[3] = e1_; v[6] = e2_; }                                                          \
+    if (lane == WAVE - 1) { v[2] = e0_; v[5] = e1_; v[8] = e2_; }                                                   \
   }
   // the eight fine p of coarse level kk: [4*half + 2*(plane i+1) + (column j+1)], loaded one level ahead of their use
+  // (every request of the walk is unconditional -- levels past the run are clamped, lanes past the row shadow the last column: a request
+  // inside a branch makes the number of outstanding loads path-dependent and the compiler then waits for vmcnt(0) at every step)
 #define LOADP(kk, v)                                                                                                \
-  if (live) {                                                                                                       \
+  {                                                                                                                 \
+    const int kq_ = (kk) <= kb ? (kk) : kb;                                                                         \
     _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                              \
-      const long long ro_ = (long long)(2 * (kk) - 2 + h_) * F.RS;                                                  \
-      if (!SK || edge0) v[4 * h_ + 0] = ld_rt(pf + o0 + ro_ + po, stream);                                          \
-      v[4 * h_ + 1] = ld_rt(pf + o0 + ro_ + pe, stream);                                                            \
-      v[4 * h_ + 2] = ld_rt(pf + o1 + ro_ + po, stream); v[4 * h_ + 3] = ld_rt(pf + o1 + ro_ + pe, stream);         \
+      const long long ro_ = (long long)(2 * kq_ - 2 + h_) * F.RS;                                                   \
+      if (!SK) v[4 * h_ + 0] = ld_rt(pf + o0 + ro_ + pol, stream);                                                  \
+      v[4 * h_ + 1] = ld_rt(pf + o0 + ro_ + pel, stream);                                                           \
+      v[4 * h_ + 2] = ld_rt(pf + o1 + ro_ + pol, stream); v[4 * h_ + 3] = ld_rt(pf + o1 + ro_ + pel, stream);       \
     }                                                                                                               \
+  }
+  // SK: the (i odd, j odd) column is read only next to a physical south / west boundary (a lane- or plane-dependent branch: kept apart)
+#define LOADP0(kk, v)                                                                                               \
+  if (SK && edge0 && live) {                                                                                        \
+    const int kq_ = (kk) <= kb ? (kk) : kb;                                                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) v[4 * h_ + 0] = ld_rt(pf + o0 + (long long)(2 * kq_ - 2 + h_) * F.RS + po, stream); \
   }
   // fine cell Q of the 2x2 block: bit 1 = plane i+1, bit 0 = column j+1 (Q = 0 is the first colour's column)
 #define PUT(k, Q, val) if (!(SK && (Q) == 0) || edge0) { const long long OO_ = ((Q) & 2) ? o1 : o0; const int PP_ = ((Q) & 1) ? pe : po;                      \
@@ -402,22 +428,25 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
     const int jf_ = ((Q) & 1) ? 2 * j2 : 2 * j2 - 1, if_ = ((Q) & 2) ? i + 1 : i;                                                                      \
     if (WR) mirror_store(F, rf, ro_, jf_, if_, PP_, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP_, w_, ph); }
   const bool edge0 = (ph.S && j2 == 1) || (ph.W && i2 == 1);  // SK: the (i odd, j odd) column of this lane is read through a mirror
+  const int ce = lane == 0 ? cm : (lane == WAVE - 1 ? cp : c0);
+  const int pol = live ? po : F.HO + (C.ny - 1), pel = live ? pe : F.EO + C.ny;  // columns the loads of a lane past the row fall on
   const double a = 9. / 16., b = 3. / 16., c = 1. / 16., d = 27. / 64., e = 9. / 64., f = 3. / 64., g = 1. / 64.;
   double pc[8], pa[8], pb[8];  // fine p of the level in work and of the next one (two levels ahead measured slower: 76 vs 71 us)
-  double lo[9], x[9], hi[9];  // coarse levels k2-1, k2, k2+1
+  double lo[9], x[9], hi[9], nw[9];  // coarse levels k2-1, k2, k2+1 and, requested one step before its first use, k2+2
 #pragma unroll
-  for (int q = 0; q < 9; q++) lo[q] = hi[q] = 0.0;
+  for (int q = 0; q < 9; q++) lo[q] = hi[q] = nw[q] = 0.0;
 #pragma unroll
   for (int q = 0; q < 8; q++) pa[q] = pb[q] = 0.0;
-  LOADP(ka, pa)
-  if (ka > 1) ROW(ka - 1, lo)
+  LOADP(ka, pa) LOADP0(ka, pa)
+  ROW(ka - 1, lo)  // (level 0 does not exist and is never used: clamped)
   ROW(ka, x)
+  ROW(ka + 1, hi)
   // one coarse level: CUR holds its fine p, NXT receives those of level kk + 1
 #define STEP(kk, CUR, NXT)                                                                                          \
   {                                                                                                                 \
     const int k2 = (kk);                                                                                            \
-    if (k2 + 1 <= kb) LOADP(k2 + 1, NXT)                                                                            \
-    if (k2 < nz) ROW(k2 + 1, hi)                                                                                    \
+    LOADP(k2 + 1, NXT) LOADP0(k2 + 1, NXT)                                                                          \
+    ROW(k2 + 2, nw)                                                                                                 \
     _Pragma("unroll") for (int q = 0; q < 8; q++) pc[q] = CUR[q];                                                   \
     if (live) {                                                                                                     \
       const double xmm = x[0], x0m = x[1], xpm = x[2], xm0 = x[3], x00 = x[4], xp0 = x[5], xmp = x[6], x0p = x[7], xpp = x[8]; \
@@ -443,16 +472,19 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
         }                                                                                                           \
       }                                                                                                             \
     }                                                                                                               \
-    _Pragma("unroll") for (int q = 0; q < 9; q++) { lo[q] = x[q]; x[q] = hi[q]; }                                   \
+    _Pragma("unroll") for (int q = 0; q < 9; q++) { lo[q] = x[q]; x[q] = hi[q]; hi[q] = nw[q]; }                    \
   }
-  for (int kk = ka; kk <= kb; kk += 2) {
+  int kk = ka;
+  for (; kk + 1 <= kb; kk += 2) {  // no branch around a step inside the loop
     STEP(kk, pa, pb)
-    if (kk + 1 <= kb) STEP(kk + 1, pb, pa)
+    STEP(kk + 1, pb, pa)
   }
+  if (kk <= kb) STEP(kk, pa, pb)
 #undef STEP
 #undef ROW
 #undef PUT
 #undef LOADP
+#undef LOADP0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,7 +821,14 @@ void mgxk_dot(hipStream_t st, const LevView *L, const double *a, const double *b
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
 }
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {
-  hipLaunchKernelGGL(k_fine2coarse, col_grid(C->ny, C->nx), dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero);
+  dim3 grd = col_grid(C->ny, C->nx);
+  const long long waves = (long long)grd.x * grd.y * 4;
+  long long nchunk = (8192 + waves - 1) / waves;  // enough waves to hide the latency of the eight loads of a level
+  if (nchunk > C->nz) nchunk = C->nz;
+  if (nchunk < 1) nchunk = 1;
+  const int KC = (int)((C->nz + nchunk - 1) / nchunk);
+  grd.z = (C->nz + KC - 1) / KC;
+  hipLaunchKernelGGL(k_fine2coarse, grd, dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero, KC);
 }
 // skip1: the caller guarantees that a four-colour relax of the fine level follows (cycles only; see k_coarse2fine_run, SK)
 void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r, int skip1) {
