@@ -312,7 +312,7 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
   if (off || F->zy == nullptr || F->nz < 2 || (F->nz & 1)) return 0;
   if (C->nx * 2 != F->nx || C->ny * 2 != F->ny) return 0;
   if ((long long)F->nx * F->ny * F->nz < mincells) return 0;
-  static const long long flatmax = getenv("MGX_RESREST_FLAT_MAX") ? atoll(getenv("MGX_RESREST_FLAT_MAX")) : 256LL * 256 * 32;
+  static const long long flatmax = getenv("MGX_RESREST_FLAT_MAX") ? atoll(getenv("MGX_RESREST_FLAT_MAX")) : 256LL * 256 * 64;
   if ((long long)F->nx * F->ny * F->nz <= flatmax) {  // no walk: one wave per S fine rows, one round trip
     static const int senv = getenv("MGX_RESREST_FLAT_S") ? atoi(getenv("MGX_RESREST_FLAT_S")) : 0;
     const int gx = (C->ny + 31) / 32, Sr = senv ? senv : 2;
