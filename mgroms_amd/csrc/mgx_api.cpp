@@ -77,7 +77,7 @@ void mgxm_rhs_vf(hipStream_t, const GeoView *, const ModelView *, double *);
 void mgxm_rhs_wf(hipStream_t, const GeoView *, const ModelView *, double *);
 void mgxm_flux_zero_face(hipStream_t, const GeoView *, double *, int face, int pl);
 void mgxm_flux_face_copy(hipStream_t, const GeoView *, double *, double *, int face, int pl, int unpack);
-void mgxm_rhs_accum(hipStream_t, const GeoView *, double *, const double *, int);
+void mgxm_rhs_accum(hipStream_t, const GeoView *, double *, const double *, const double *, const double *);
 void mgxm_correct_uvw(hipStream_t, const GeoView *, const double *, const ModelView *);
 // native RCCL transport (mgx_rccl.cpp)
 const char *mgxr_last_error(void);
@@ -149,7 +149,7 @@ struct State {
   long long n_p2p = 0;
   int p2p_failed = 0;       // a wait of this rank timed out since the ranks last agreed (global_sum): reported collectively there
   int p2p_test_drop = 0;    // test hook (option "p2p_test_drop" = n): the n-th halo exchange from now does not raise its flags
-  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_fx = nullptr, *d_bm = nullptr;  // d_fx, d_bm: model-layout scratch (flux, divergence / pressure)
+  double *d_u = nullptr, *d_v = nullptr, *d_w = nullptr, *d_fx = nullptr, *d_fy = nullptr, *d_fz = nullptr, *d_bm = nullptr;  // model-layout scratch: the three fluxes of compute_rhs, divergence / pressure
   // the mask handed to nhydro_solve / nhydro_check_nondivergence on THIS call (nhydro.f90:72,82,98): staging copy in the
   // caller's layout and the i-fastest copy the model-space kernels read; call_mask = a mask came with the current call
   double *d_rmask_ref = nullptr, *d_rmask_m = nullptr; bool call_mask = false;
@@ -861,20 +861,20 @@ int set_call_mask(const double *rmask, bool dev) {
 // fill_halo(1,uf,lbc_null='u') / fill_halo(1,vf,lbc_null='v') (mg_compute_rhs.f90:171,272), reduced to the entries the
 // divergence reads: the first and last face.  Physical side: zero flux.  Neighbour: my last face is the neighbour's first
 // face, computed over there from its own copy of the shared velocity (the reference takes that value too).
-int flux_halo(Level &L, int face) {
+int flux_halo(Level &L, int face, double *fx) {
   const int lo = face == 0 ? L.neighb[3] : L.neighb[0], hi = face == 0 ? L.neighb[1] : L.neighb[2];  // W,E or S,N
   const int last = face == 0 ? L.nx + 1 : L.ny + 1, cnt = L.nz * (face == 0 ? L.ny : L.nx);
-  if (lo < 0) { mgxm_flux_zero_face(S.stream, &L.g, S.d_fx, face, 1); S.n_launch++; }
-  if (hi < 0) { mgxm_flux_zero_face(S.stream, &L.g, S.d_fx, face, last); S.n_launch++; }
+  if (lo < 0) { mgxm_flux_zero_face(S.stream, &L.g, fx, face, 1); S.n_launch++; }
+  if (hi < 0) { mgxm_flux_zero_face(S.stream, &L.g, fx, face, last); S.n_launch++; }
   if (lo < 0 && hi < 0) return 0;
   if ((size_t)cnt > S.xbuf_n) return fail("halo buffer too small");
   // the exchange callback moves equal counts both ways with every peer: the unused direction carries a zero buffer
   int n = 0, peer[2], cn[2]; double *sb[2], *rb[2];
-  if (lo >= 0) { mgxm_flux_face_copy(S.stream, &L.g, S.d_fx, S.xbuf[0], face, 1, 0); S.n_launch++; peer[n] = lo; cn[n] = cnt; sb[n] = S.xbuf[0]; rb[n] = S.xbuf[8]; n++; }
+  if (lo >= 0) { mgxm_flux_face_copy(S.stream, &L.g, fx, S.xbuf[0], face, 1, 0); S.n_launch++; peer[n] = lo; cn[n] = cnt; sb[n] = S.xbuf[0]; rb[n] = S.xbuf[8]; n++; }
   if (hi >= 0) { peer[n] = hi; cn[n] = cnt; sb[n] = S.xbuf[2]; rb[n] = S.xbuf[9]; n++; }
   if (hi >= 0) HIPCHK(hipMemsetAsync(S.xbuf[2], 0, (size_t)cnt * sizeof(double), S.stream));
   CHK(exchange(n, peer, sb, rb, cn));
-  if (hi >= 0) { mgxm_flux_face_copy(S.stream, &L.g, S.d_fx, S.xbuf[9], face, last, 1); S.n_launch++; }
+  if (hi >= 0) { mgxm_flux_face_copy(S.stream, &L.g, fx, S.xbuf[9], face, last, 1); S.n_launch++; }
   return 0;
 }
 
@@ -885,13 +885,11 @@ int compute_rhs_dev() {
   ModelView M = model_view();
   HIPCHK(hipMemsetAsync(L.v.b, 0, L.n3js * sizeof(double), S.stream));
   mgxm_rhs_uf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  if (!S.par.bmask) CHK(flux_halo(L, 0));  // mg_compute_rhs.f90:170-172
-  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 0); S.n_launch++;
-  mgxm_rhs_vf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  if (!S.par.bmask) CHK(flux_halo(L, 1));  // :271-273
-  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 1); S.n_launch++;
-  mgxm_rhs_wf(S.stream, &L.g, &M, S.d_fx); S.n_launch++;
-  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, 2); S.n_launch++;
+  if (!S.par.bmask) CHK(flux_halo(L, 0, S.d_fx));  // mg_compute_rhs.f90:170-172
+  mgxm_rhs_vf(S.stream, &L.g, &M, S.d_fy); S.n_launch++;
+  if (!S.par.bmask) CHK(flux_halo(L, 1, S.d_fy));  // :271-273
+  mgxm_rhs_wf(S.stream, &L.g, &M, S.d_fz); S.n_launch++;
+  mgxm_rhs_accum(S.stream, &L.g, S.d_bm, S.d_fx, S.d_fy, S.d_fz); S.n_launch++;  // :173, :274, :362-370 in one pass, same order
   mgxm_js_model(S.stream, &L.v, L.v.b, S.d_bm, 1); S.n_launch++;  // interior of b in the solver's layout
   return 0;
 }
@@ -1325,6 +1323,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   CHK(dmalloc(&S.d_v, (size_t)(L1.nx + 2) * (L1.ny + 1) * L1.nz));
   CHK(dmalloc(&S.d_w, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   CHK(dmalloc(&S.d_fx, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  CHK(dmalloc(&S.d_fy, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
+  CHK(dmalloc(&S.d_fz, (size_t)(L1.nx + 2) * (L1.ny + 2) * (L1.nz + 1)));
   CHK(dmalloc(&S.d_bm, (size_t)(L1.nx + 2) * (L1.ny + 2) * L1.nz));
   CHK(dmalloc(&S.d_rmask_ref, (size_t)(L1.nx + 2) * (L1.ny + 2))); CHK(dmalloc(&S.d_rmask_m, (size_t)(L1.nx + 2) * (L1.ny + 2)));
   S.call_mask = false;
