@@ -793,7 +793,7 @@ int define_matrices() {
     mgxs_zr_zw(S.stream, &L.g, S.hlim, S.theta_b, S.theta_s); S.n_launch++;
     CHK(rl_fill_halo(L, L.g.zr, L.nz, 2, 0));
     CHK(rl_fill_halo(L, L.g.zw, L.nz + 1, 2, 0));
-    HIPCHK(hipMemsetAsync(L.g.cA, 0, (size_t)8 * L.nz * (L.ny + 2) * (L.nx + 2) * sizeof(double), S.stream));
+    // (no clearing of the cA scratch: k_cA_offdiag stores every slot of every cell, zeros included)
     L.g.bmask = S.par.bmask ? 1 : 0;
     if (l > 0) {  // boundary mask of a coarse level = 1, 0 in the physical halo when bmask (:157-161, fill_halo_2D_bmask)
       rect(L.g.rmask, 0, 5, 1, 1, L.ny, 0, L.ny + 1, 0, L.nx + 1);
