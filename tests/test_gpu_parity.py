@@ -520,6 +520,27 @@ def test_async_operators_same_bits(mg):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("dims", [(64, 96, 32), (128, 64, 16)])
+def test_transfer_kernel_variants_same_bits(dims):
+    """The A/B switches of round 3's transfer kernels (read from the environment once per process, so each variant is a process of its own):
+    residual+restriction by the walk on every level / without the walk on every level / four rows per wave, the walk's look-ahead depths,
+    the prolongation's run length, the model kernels' run length -- the same bits as the defaults for b, every level's p and b after two
+    V-cycles, after two F-cycle iterations, the history and the corrected u, v, w."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    variants = [{}, {"MGX_RESREST_FLAT_MAX": "0"}, {"MGX_RESREST_FLAT_MAX": "100000000"}, {"MGX_RESREST_FLAT_MAX": "100000000", "MGX_RESREST_FLAT_S": "4"},
+                {"MGX_RESREST_FLAT_MAX": "0", "MGX_RESREST_AHEAD": "12"}, {"MGX_RESREST_FLAT_MAX": "0", "MGX_RESREST_AHEAD": "21"},
+                {"MGX_C2F_KC": "1"}, {"MGX_C2F_KC": "4"}, {"MGX_MODEL_KR": "8"}, {"MGX_MODEL_KR": "1000"}]
+    digests = []
+    for var in variants:
+        env = dict(os.environ); env.update(var)
+        out = subprocess.run([sys.executable, os.path.join(here, "_gpu_variant_worker.py")] + [str(d) for d in dims], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (var, out.stdout[-2000:], out.stderr[-2000:])
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    for var, d in zip(variants, digests):
+        assert d == digests[0], var
+
+
 def test_fortran_harness_bmask(mg, tmp_path):
     """bmask = .true. through the Fortran boundary: the driver masks the boundary ring of rmask as the reference's does
     (fill_halo_2D_bmask(1,rmask) before nhydro_matrices, mg_testseamount.f90 / mg_mpi_exchange.f90:357-391; `bmask` read from the
