@@ -9,7 +9,8 @@
 // registers, shares the pair's p / slope / coefficient values between its two residuals (24 loads per row = 12 per
 // cell), rebuilds the diagonal from the couplings (as the smoother does, mgx_relax.hip), and the 8-cell sum is closed with
 // the partner lane's two values (one cross-lane exchange per row): no r traffic, no diagonal stream, one launch.
-// Measured (rocprofv3, MI355X): 512x512x64 250 us against 279 + 36 for the two kernels; 256x256x32 45 against 47 + 13.
+// Measured (rocprofv3, MI355X): 512x512x64 211-224 us against 279 + 36 for the two kernels (round 2: 236-250 with guarded look-ahead);
+// levels of up to 256x256x64 cells take k_residual_restrict_flat below (256x256x32: 24 us against 47 + 13).
 // The residuals and the 8-term sum use the reference's expressions in the reference's order: b_c is bit-identical to
 // compute_residual followed by fine2coarse.  Matrix-free cross terms (needs the slopes zy, zx: the matrix must be the one
 // define_matrices built); other cases keep the two separate kernels.
@@ -77,8 +78,8 @@ __device__ __forceinline__ void load_r(RowR &r, const LevView &F, const Geo &g, 
 }  // namespace
 
 // grid: 1-D, gx j-chunks of 32 coarse columns x gy groups of blockDim.y coarse planes, XCD-aware as k_relax_nz.
-// One wave per SIMD (360 registers: four window rows + two row buffers, so that the next rows load while one is computed;
-// squeezed to 256 registers for two waves per SIMD it spills and loses: 250 vs 236 us at 512x512x64, 45 vs 78 at 256x256x32).
+// One wave per SIMD (AW = AR = 1: four window rows + two row buffers, ~450 registers with the requests kept ahead of their use;
+// squeezed to 256 registers for two waves per SIMD it spills and loses: 250 vs 236 us at 512x512x64 in round 2).
 template <bool REAL, int AW, int AR>
 __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx, int gy) {
   int bx, by;
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
       e[jj][4] = a8[g.o + c]; e[jj][5] = F.p[g.om + jm]; e[jj][6] = a8[g.op + jp]; e[jj][7] = F.p[g.op + jp];
     }
   }
-  // Look-ahead: the window rows are requested AW steps and the rows' own values AR steps before their first use.  With AW = AR = 1 (one
-  // wave per SIMD, ~45 requests in flight) a step cost a whole memory round trip: 4300 cycles per row at 512x512x64.
+  // Look-ahead: the window rows are requested AW steps and the rows' own values AR steps before their first use (A/B of the depths,
+  // scripts/probe/ab_resrest_ahead.sh: (1,1) 224 us, (1,2) 233, (2,1) 225 -- once the requests are unconditional, below, the depth is
+  // not what bounds the kernel).
   constexpr int NWB = 3 + AW, NRB = 1 + AR;  // buffers: rows k-1, k, k+1 + AW ahead; row k + AR ahead
   constexpr int U = (NWB % NRB == 0) ? NWB : NWB * NRB;  // steps after which both rotations are back where they started
   static_assert(U <= 12, "unroll");
