@@ -35,6 +35,9 @@ int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_wave_fused(hipStream_t, const LevView *, const LevView *, int, int, int, Sides, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
+void mgxk_rbseq_setup(hipStream_t, const LevView *);
+int mgxk_rbseq_scan(hipStream_t, const LevView *, int);
+void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
@@ -159,6 +162,7 @@ struct State {
   int tictoc = 0;       // per-(level,name) GPU timers in the shape of mg_tictoc.f90
   int rb_chain = 1;     // red-black: chained k=1 snapshots on closed levels (0 = one snapshot launch per colour pass, for A/B tests)
   int keep_r = 0;       // cycles also store the interpolated correction in the fine r (dead state of the reference's coarse2fine)
+  int rb_seq = 1;       // red-black with cmatrix='real' in the reference's sequential order by the parallel pass + a scan over the planes of the k=1 couplings + a rank-one correction per column (mgx_rbseq.hip): within a few ulp of mg_relax.f90:170-186, the DEFAULT; 0 = the plain parallel pass (old same-colour diagonals everywhere, 1e-4 per sweep away)
   int rb_exact = 0;     // red-black with cmatrix='real' in the reference's SEQUENTIAL order (plane after plane): bit-identical to mg_relax.f90:170-186, slow
   int exact_halos = 0;  // MGX_EXACT_HALOS=1: exchange r and b halos eagerly like the reference
   int no_mf = 0;      // MGX_NO_MF=1: always use the stored slots 3,5,6,8 (A/B tests)
@@ -494,7 +498,9 @@ int relax(int lev, int nsweeps) {
   }
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   const int exact = S.method == M_RB && S.real && S.rb_exact;
-  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact)) { S.n_launch++; return 0; }
+  // sequential-order red-black (mgx_rbseq.hip); the one-workgroup kernels of the small levels run the reference's plane loop itself
+  const int seq = S.method == M_RB && S.real && S.rb_seq && !exact && L.v.gk != nullptr;
+  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact || seq)) { S.n_launch++; return 0; }
   const bool closed = all_physical(ph);
   // closed mid levels, four colours: the whole call in one persistent launch, one workgroup per plane (mgx_relax_ks.hip: k_relax_ksp)
   if (S.method == M_FC && closed && S.use_ksp && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr, S.ksp_test_stall)) {
@@ -521,14 +527,21 @@ int relax(int lev, int nsweeps) {
       // pass (snapshot).  On a closed level the register kernels write the next sweep's snapshot themselves (two buffers
       // swapped per sweep: a pass reads only entries of its own colour, which the other colour's pass never touches), so
       // one snapshot launch per relax call suffices; with neighbours the halo part changes after every exchange.
-      const bool chain = S.rb_chain && S.real && closed && mgxk_has_reg_kernel(&L.v);
+      const bool chain = S.rb_chain && S.real && closed && mgxk_has_reg_kernel(&L.v) && !seq;
       if (chain) {
         if (it == 1) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
         L.v.p1w = (L.v.p1 == p1a) ? L.p1b : p1a;
       }
       for (int rb = 1; rb <= 2; rb++) {
         if (S.real && !chain) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
-        const int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
+        int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
+        if (seq) {
+          // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
+          // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
+          if (!mgxk_rbseq_scan(S.stream, &L.v, rb)) return fail("rb_seq: level %d (ny = %d) has no scan instance; set option rb_exact or rb_seq = 0", lev, L.ny);
+          mgxk_rbseq_apply(S.stream, &L.v, rb, ph, 0); S.n_launch += 3;
+          fused = 1;  // the correction stores the physical images of every column it updates
+        }
         CHK(fill_halo_js(L, L.v.p, fused));
       }
       if (chain) { L.v.p1 = L.v.p1w; L.v.p1w = nullptr; if (it == nsweeps) L.v.p1 = p1a; }
@@ -649,7 +662,7 @@ int coarse2fine(int lev, bool keep_r = true, bool skip1 = false) {
 // the fused kernel took the job (same bits as the separate operators), 0 = run them.
 int relax_fused(int lev, int nsweeps, int flags) {
   if (lev >= S.nlevs || !S.use_small || !S.use_fuse || S.method == M_GS || S.tictoc || S.keep_r || S.exact_halos || !S.linear) return 0;
-  if (S.method == M_RB && S.real && S.rb_exact) return 0;
+  if (S.method == M_RB && S.real && (S.rb_exact || S.rb_seq)) return 0;  // sequential-order red-black: the plane loop of k_relax_reg
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0}, phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0};
   if (!all_physical(phf) || !all_physical(phc) || C.gather) return 0;
@@ -824,6 +837,7 @@ int define_matrices() {
     if (L.nz <= 1024) { mgxk_convert8(S.stream, &L.v, L.g.cA); S.n_launch++; }  // LDS-tiled transposition, one slot per block
     else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), 1, 0, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
+    if (L.v.gk) { mgxk_rbseq_setup(S.stream, &L.v); S.n_launch++; }
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     if (L.nz <= 1024) { mgxk_convert2(S.stream, &L.v, L.zy_store, L.zx_store, L.g.szy); S.n_launch++; }
     else { mgxk_convert(S.stream, &L.v, L.zy_store, L.g.szy, 1, 0, 0); mgxk_convert(S.stream, &L.v, L.zx_store, L.g.szx, 1, 0, 0); S.n_launch += 2; }
@@ -1212,11 +1226,11 @@ void mgx_clean(void) {
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   if (S.kerr) (void)hipHostFree(S.kerr);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   S = State();
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1274,6 +1288,11 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int q = 0; q < 2; q++) CHK(dmalloc(&L.zg_store[q], (size_t)(L.nx + 2) * L.v.RS));
     for (int q = 2; q < 4; q++) CHK(dmalloc(&L.zg_store[q], (size_t)L.nz + 1));
     L.v.dx2 = L.v.dy2 = nullptr; L.v.cffr = L.v.csr = nullptr;
+    L.v.gk = L.v.ag5 = L.v.ag8 = L.v.u1 = nullptr;
+    if (S.method == M_RB && S.real) {  // sequential-order red-black (mgx_rbseq.hip): +8 B per cell
+      CHK(dmalloc(&L.v.gk, L.n3js));
+      CHK(dmalloc(&L.v.ag5, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.ag8, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
+    }
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
     CHK(dmalloc(&L.g.dx, n2)); CHK(dmalloc(&L.g.dy, n2)); CHK(dmalloc(&L.g.zeta, n2)); CHK(dmalloc(&L.g.h, n2));
@@ -1337,6 +1356,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
   if (getenv("MGX_TICTOC")) S.tictoc = 1;
   if (getenv("MGX_RB_EXACT")) S.rb_exact = atoi(getenv("MGX_RB_EXACT"));
+  if (getenv("MGX_RB_SEQ")) S.rb_seq = atoi(getenv("MGX_RB_SEQ"));
   S.inited = true;
   if (S.verbose && S.rank == 0) {  // read_nhnamelist prints (mg_namelist.f90:108-124) and print_grids (mg_grids.f90:741-762)
     printf(" Non hydrostatic parameters:\n   - solver_prec   : %g\n   - solver_maxiter: %d\n   - nsmall        : %d\n   - ns_coarsest   : %d\n"
@@ -1504,6 +1524,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "verbose")) S.verbose = value;
   else if (streq(name, "rb_chain")) S.rb_chain = value;
   else if (streq(name, "rb_exact")) S.rb_exact = value;
+  else if (streq(name, "rb_seq")) S.rb_seq = value;
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "ksp")) S.use_ksp = value;
@@ -1538,6 +1559,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "verbose")) *value = S.verbose;
   else if (streq(name, "rb_chain")) *value = S.rb_chain;
   else if (streq(name, "rb_exact")) *value = S.rb_exact;
+  else if (streq(name, "rb_seq")) *value = S.rb_seq;
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "ksp")) *value = S.use_ksp;
@@ -1633,6 +1655,7 @@ int mgx_set_field(int lev, int field, const double *host) {
     HIPCHK(hipMemcpyAsync(S.ref_scratch, host, 8 * n3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
     for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 0);
     mgxs_pivots(S.stream, &L.v);
+    if (L.v.gk) mgxk_rbseq_setup(S.stream, &L.v);
     L.v.zy = L.v.zx = nullptr;  // a user-supplied matrix is used as stored
     L.v.m4 = nullptr;
     S.have_matrix = true;

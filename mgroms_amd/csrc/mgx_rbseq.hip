@@ -1,0 +1,229 @@
+// Red-black smoothing in the reference's SEQUENTIAL order at streaming speed (option "rb_seq"; mg_relax.f90:151-190 with cmatrix='real').
+//
+// The reference sweeps the columns of a colour plane after plane (do i; do j, mg_relax.f90:173-176).  With cmatrix='real' a column's
+// bottom row reads four neighbours of its OWN colour (:271-276): p(1,j+-1,i-1), which the loop has already updated, and p(1,j+-1,i+1),
+// which it has not.  That is the only coupling between columns of one colour, it acts on the right-hand side of row k = 1 only, it comes
+// from plane i-1 only, and the column solve is linear in its right-hand side.  So, per colour:
+//   (a) the parallel colour pass (every kernel of mgx_relax*.hip, k=1 diagonals read from the snapshot p1 = "old" everywhere) gives y;
+//   (b) d0 = y(1) - p1 (k_rbseq_d0), then ONE wave walks the planes i = 1..nx (k_rbseq_scan):
+//         u(j,i) = d0(j,i) - ag5(j,i) u(j+1,i-1) - ag8(j,i) u(j-1,i-1),   ag5|8 = g(1,j,i) cA(5|8,1,j,i),  g = T^-1 e1
+//       u = new minus old bottom value of the column in the sequential order (zero in the halo: a halo cell is refreshed after the
+//       colour, mg_relax.f90:181, on one rank and on several alike);
+//   (c) p(:,j,i) = y(:,j,i) + g(:,j,i) s(j,i),  s = -cA(5,1,j,i) u(j+1,i-1) - cA(8,1,j,i) u(j-1,i-1)   (k_rbseq_apply, with the mirrors).
+// Not bit-identical to the sequential loop (the same sum in another association: a few ulp), far inside north_star's 1e-10; the
+// bit-exact order stays available as "rb_exact" (one launch per plane) and is what the tests compare against.
+//
+// Why one wave: the recurrence is sequential in i by nature (the cone of (j,i) widens by one column per plane in both directions), a
+// step is two fused multiply-adds per column, and what limits the walk is how fast ONE compute unit takes in 24 B per column
+// (~32 B/clk): the wave keeps D planes of operands in flight in registers (CPL columns per lane, contiguous, so the neighbours
+// j+-1 are the lane's own registers but for one value that crosses to the next lane by a DPP wave shift).
+#include <cstdlib>
+
+#include "mgx_device.h"
+
+// g = T^-1 e1 of every interior column with tridiag's own recurrences (mg_relax.f90:320-332; bet, gam from k_pivots), and the two
+// multipliers of the scan.  One thread per column, lanes along j.
+__global__ void k_rbseq_setup(LevView L) {
+  const int jj = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (jj > L.ny || i > L.nx) return;
+  const int c = jpos(L, jj);
+  const long long o = (long long)i * L.plane + c;
+  const double *__restrict__ dd = L.cA[1];
+  double x = L.bet[o];  // xc(1) = b(1)*bet, b = e1
+  L.gk[o] = x;
+  for (int k = 2; k <= L.nz; k++) {
+    const long long ko = o + (long long)(k - 1) * L.RS;
+    x = (0.0 - dd[ko] * x) * L.bet[ko];
+    L.gk[ko] = x;
+  }
+  for (int k = L.nz - 1; k >= 1; k--) {
+    const long long ko = o + (long long)(k - 1) * L.RS;
+    x = L.gk[ko] - L.gam[ko + L.RS] * x;
+    L.gk[ko] = x;
+  }
+  const long long q = (long long)i * L.RS + c;
+  L.ag5[q] = x * L.cA[4][o];
+  L.ag8[q] = x * L.cA[7][o];
+}
+
+// position of the first column of the colour inside a row of plane i: odd j -> HO + jh, even j -> EO + 1 + jh  (jh = 0..ny/2-1)
+__device__ __forceinline__ int rb_jodd(int i, int rb) { return ((i + rb) & 1) == 0; }  // mg_relax.f90:174: j = 1+mod(i+rb,2),ny,2
+
+// d0 = y(k=1) - snapshot, for the columns of colour rb
+__global__ void k_rbseq_d0(LevView L, int rb) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (jh >= (L.ny >> 1) || i > L.nx) return;
+  const int c = rb_jodd(i, rb) ? L.HO + jh : L.EO + 1 + jh;
+  const long long q = (long long)i * L.RS + c;
+  L.u1[q] = L.p[(long long)i * L.plane + c] - L.p1[q];
+}
+
+__device__ __forceinline__ double wave_shr1(double x) {  // lane n takes lane n-1's value, lane 0 takes 0
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double x) {  // lane n takes lane n+1's value, lane 63 takes 0
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int N> struct VecD { double v[N]; };
+
+// The walk over the planes.  CPL columns per lane; D planes of operands in flight (nx is a multiple of D: the wrapper picks D);
+// RBP = rb & 1 makes the j parity of a plane a compile-time property of its ring slot (planes start at the odd i = 1, D is even);
+// FULL: the colour's half-row is exactly 64*CPL columns (vector accesses, no lane predicates).
+template <int CPL, int D, int RBP, bool FULL>
+__global__ __launch_bounds__(64) void k_rbseq_scan(LevView L) {
+  const int lane = threadIdx.x, nyh = L.ny >> 1, nx = L.nx;
+  const int jh0 = lane * CPL;
+  const long long RS = L.RS;
+  double *__restrict__ u1 = L.u1;
+  const double *__restrict__ g5 = L.ag5, *__restrict__ g8 = L.ag8;
+  VecD<CPL> rd[D], r5[D], r8[D];
+  double up[CPL];
+  bool ok[CPL];
+  int jc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; q++) { up[q] = 0.0; ok[q] = jh0 + q < nyh; jc[q] = ok[q] ? jh0 + q : nyh - 1; }
+  // every request is unconditional (planes past nx clamp to nx, lanes past the row to its last column): the waits stay counted
+#define LOADP(ip, slot)                                                                                          \
+  {                                                                                                              \
+    const int i_ = (ip) <= nx ? (ip) : nx;                                                                       \
+    const long long q_ = (long long)i_ * RS + (((((slot) + 1 + RBP) & 1) == 0) ? L.HO : L.EO + 1);               \
+    if (FULL) {                                                                                                  \
+      __builtin_memcpy(&rd[slot], u1 + q_ + jh0, sizeof(VecD<CPL>));                                             \
+      __builtin_memcpy(&r5[slot], g5 + q_ + jh0, sizeof(VecD<CPL>));                                             \
+      __builtin_memcpy(&r8[slot], g8 + q_ + jh0, sizeof(VecD<CPL>));                                             \
+    } else {                                                                                                     \
+      _Pragma("unroll") for (int q = 0; q < CPL; q++) {                                                          \
+        rd[slot].v[q] = u1[q_ + jc[q]]; r5[slot].v[q] = g5[q_ + jc[q]]; r8[slot].v[q] = g8[q_ + jc[q]];          \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+#pragma unroll
+  for (int d = 0; d < D; d++) LOADP(1 + d, d)
+  for (int i0 = 1; i0 <= nx; i0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int i = i0 + d;
+      constexpr int dummy = 0; (void)dummy;
+      const bool jodd = (((d + 1 + RBP) & 1) == 0);  // = rb_jodd(i, rb): i0 is odd
+      VecD<CPL> un;
+      // odd j (position HO + jh):  j+1 <-> previous plane's jh,     j-1 <-> its jh - 1
+      // even j (EO + 1 + jh):      j+1 <-> previous plane's jh + 1, j-1 <-> its jh
+      const double edge = jodd ? wave_shr1(up[CPL - 1]) : wave_shl1(up[0]);
+#pragma unroll
+      for (int q = 0; q < CPL; q++) {
+        double ua, ub;  // u(j+1,i-1), u(j-1,i-1)
+        if (jodd) { ua = up[q]; ub = q > 0 ? up[q > 0 ? q - 1 : 0] : edge; }
+        else { ub = up[q]; ua = q < CPL - 1 ? up[q < CPL - 1 ? q + 1 : 0] : edge; }
+        double t = __builtin_fma(-r5[d].v[q], ua, rd[d].v[q]);
+        t = __builtin_fma(-r8[d].v[q], ub, t);
+        un.v[q] = (FULL || ok[q]) ? t : 0.0;
+      }
+      const long long qo = (long long)i * RS + (jodd ? L.HO : L.EO + 1);
+      if (FULL) __builtin_memcpy(u1 + qo + jh0, &un, sizeof(VecD<CPL>));
+      else {
+#pragma unroll
+        for (int q = 0; q < CPL; q++) if (ok[q]) u1[qo + jh0 + q] = un.v[q];
+      }
+#pragma unroll
+      for (int q = 0; q < CPL; q++) up[q] = un.v[q];
+      LOADP(i + D, d)
+    }
+  }
+#undef LOADP
+}
+
+// (c): p(:,j,i) += g(:,j,i) * s(j,i) for the columns of colour rb, with the physical mirrors (the pass wrote y into them), and -- SNAPW --
+// the new bottom value into the snapshot p1 (and its mirrors), so that a closed level needs no snapshot launch before the next pass.
+// One wave = 64 columns of a plane x the rows [kz*KR, (kz+1)*KR).
+template <int KU, bool SNAPW>
+__global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph, int KR, int nt) {
+  const int jh = blockIdx.x * WAVE + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  if (jh >= (L.ny >> 1) || i > L.nx) return;
+  const int jodd = rb_jodd(i, rb);
+  int c, jm, jp;
+  if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+  else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+  const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
+  const long long o = (long long)i * L.plane;
+  const long long qm = (long long)(i - 1) * L.RS;
+  const double s = 0.0 - L.cA[4][o + c] * L.u1[qm + jp] - L.cA[7][o + c] * L.u1[qm + jm];
+  double *__restrict__ p = L.p;
+  const double *__restrict__ g = L.gk;
+  const int k0 = blockIdx.z * KR;
+  for (int kb = k0; kb < k0 + KR; kb += KU) {
+    double pv[KU], gv[KU];
+#pragma unroll
+    for (int t = 0; t < KU; t++) {
+      const long long ko = o + (long long)(kb + t) * L.RS + c;
+      pv[t] = p[ko]; gv[t] = ld_rt(g + ko, nt);
+    }
+#pragma unroll
+    for (int t = 0; t < KU; t++) {
+      const long long ro = (long long)(kb + t) * L.RS;
+      const double v = pv[t] + gv[t] * s;
+      p[o + ro + c] = v;
+      mirror_store(L, p, ro, j, i, c, v, ph);
+      if (SNAPW && kb + t == 0) {
+        LevView L2 = L; L2.plane = L.RS;  // the snapshot: one row per plane
+        L.p1[(long long)i * L.RS + c] = v;
+        mirror_store(L2, L.p1, 0, j, i, c, v, ph);
+      }
+    }
+  }
+}
+
+extern "C" {
+
+void mgxk_rbseq_setup(hipStream_t st, const LevView *L) {
+  hipLaunchKernelGGL(k_rbseq_setup, dim3((L->ny + 63) / 64, (L->nx + 3) / 4), dim3(64, 4), 0, st, *L);
+}
+
+// (b): d0 and the walk; returns 0 when the level has no instance (more than 1024 columns per half-row): the caller then runs the planes one by one
+int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
+  const int nyh = L->ny / 2, nx = L->nx;
+  if (L->gk == nullptr || nyh > 16 * WAVE || (nx & 1)) return 0;
+  hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
+  const int rbp = rb & 1;
+#define SCAN_CASE(CPLV, DV, FULLV)                                                                                   \
+  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV>), dim3(1), dim3(WAVE), 0, st, *L);                \
+    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV>), dim3(1), dim3(WAVE), 0, st, *L);                    \
+    return 1; }
+  // ring depth: as many planes as the register file takes (3 * CPL * D doubles), a divisor of nx
+#define SCAN_CPL(CPLV, DMAX)                                                                                         \
+  { const bool full = nyh == CPLV * WAVE;                                                                            \
+    if (nx % DMAX == 0) { if (full) SCAN_CASE(CPLV, DMAX, true) else SCAN_CASE(CPLV, DMAX, false) }                 \
+    if (nx % 4 == 0) { if (full) SCAN_CASE(CPLV, 4, true) else SCAN_CASE(CPLV, 4, false) }                          \
+    if (full) SCAN_CASE(CPLV, 2, true) else SCAN_CASE(CPLV, 2, false) }
+  if (nyh <= WAVE) SCAN_CPL(1, 16)
+  if (nyh <= 2 * WAVE) SCAN_CPL(2, 16)
+  if (nyh <= 4 * WAVE) SCAN_CPL(4, 16)
+  if (nyh <= 8 * WAVE) SCAN_CPL(8, 8)
+  SCAN_CPL(16, 4)
+#undef SCAN_CPL
+#undef SCAN_CASE
+}
+
+void mgxk_rbseq_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw) {
+  const int nyh = L->ny / 2, nz = L->nz;
+  const int ku = nz % 8 == 0 ? 8 : (nz % 4 == 0 ? 4 : 2);
+  // rows per wave: enough waves to fill the chip on the large levels, whole columns on the small ones
+  int kr = nz;
+  const long long waves = (long long)((nyh + WAVE - 1) / WAVE) * L->nx;
+  while (kr > ku && kr % 2 == 0 && (kr / 2) % ku == 0 && waves * (nz / kr) < 4096) kr /= 2;
+  const dim3 grd((nyh + WAVE - 1) / WAVE, (L->nx + 3) / 4, nz / kr), blk(WAVE, 4);
+  const int nt = level_streams(L);
+#define APPLY_CASE(KUV)                                                                                              \
+  { if (snapw) hipLaunchKernelGGL((k_rbseq_apply<KUV, true>), grd, blk, 0, st, *L, rb, ph, kr, nt);                 \
+    else hipLaunchKernelGGL((k_rbseq_apply<KUV, false>), grd, blk, 0, st, *L, rb, ph, kr, nt); }
+  if (ku == 8) APPLY_CASE(8) else if (ku == 4) APPLY_CASE(4) else APPLY_CASE(2)
+#undef APPLY_CASE
+}
+
+}  // extern "C"

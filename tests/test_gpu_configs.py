@@ -95,10 +95,19 @@ def test_rb_exact_matches_reference_history_and_oracle(mg, golden):
     p = mg.grid(1).p
     assert np.array_equal(p, o.field("p"))
     assert np.isclose((p[1:-1, 1:-1, :] ** 2).sum(), g["sum_p2"], rtol=1e-12)
-    # the default (parallel) sweep on the same problem differs, within the stated tolerance
+    # the plain parallel sweep on the same problem differs, within the stated tolerance
     _gpu(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
-    n2, hist2 = mg.solve_p(1e-6, 50)
+    mg.nhydro.set_option("rb_seq", 0)
+    try:
+        n2, hist2 = mg.solve_p(1e-6, 50)
+    finally:
+        mg.nhydro.set_option("rb_seq", 1)
     assert n2 == n and not np.array_equal(hist2, hist) and np.all(np.abs(hist2[1:] - ref) <= 5e-5 * ref)
+    # and the default (sequential order at speed, mgx_rbseq.hip) is the exact one up to a few ulp
+    _gpu(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
+    n3, hist3 = mg.solve_p(1e-6, 50)
+    assert n3 == n and _hist_close(hist3, hist, rtol=1e-10)
+    assert np.abs(mg.grid(1).p - p).max() <= 1e-10 * np.abs(p).max()
 
 
 @pytest.mark.parametrize("dims", [(32, 16, 8), (16, 64, 4), (128, 32, 8)])
@@ -131,21 +140,38 @@ def test_relax_rb_parallel_deviation_is_small(mg):
     o = _oracle(64, 64, 16, relax_method="RB")
     o.field("p")[...] = p0
     o.field("b")[...] = b0
-    mg.relax(1, 1); o.relax(1, 1)
+    mg.nhydro.set_option("rb_seq", 0)
+    try:
+        mg.relax(1, 1); o.relax(1, 1)
+    finally:
+        mg.nhydro.set_option("rb_seq", 1)
     a, c = mg.grid(1).p, o.field("p")
     d = np.abs(a - c).max() / np.abs(c).max()
     assert 0 < d <= 1e-4, d
+    # the default sweep from the same state: the sequential order itself
+    mg.grid(1).set("p", p0); mg.fill_halo(1, "p")
+    mg.relax(1, 1)
+    assert np.abs(mg.grid(1).p - c).max() <= 1e-13 * np.abs(c).max()
 
 
 # ---- BASELINE config 2: seamount 256x256x32, red-black ---------------------------------------------------------------
 def test_config2_rb_256x256x32(mg, golden):
     ref = golden["seamount_256x256x32_RB_printed"]
-    # (a) the default (parallel) sweep, 50 iterations as the reference runs it (it stops at maxiter)
+    # (a) the default (sequential order at speed), 50 iterations as the reference runs it (it stops at maxiter)
     _gpu(mg, 256, 256, 32, relax_method="RB", solver_prec=1e-8)
     n, hist = mg.solve_p(1e-8, 50)
     assert n == 50 == ref["nite"]
     assert np.all(np.abs(hist[1:6] - np.array(ref["first5"])) <= 6e-4), hist[1:6]       # printed with 3 digits
-    assert abs(hist[50] - ref["res50"]) <= 0.0006e-5 + 5e-5 * ref["res50"], hist[50]    # 0.426E-05
+    assert abs(hist[50] - ref["res50"]) <= 0.0006e-5, hist[50]                          # 0.426E-05
+    hist_seq = hist.copy()
+    # (a') the plain parallel sweep: the same printed digits, 5e-5 away
+    _gpu(mg, 256, 256, 32, relax_method="RB", solver_prec=1e-8)
+    mg.nhydro.set_option("rb_seq", 0)
+    try:
+        n, hist = mg.solve_p(1e-8, 50)
+    finally:
+        mg.nhydro.set_option("rb_seq", 1)
+    assert n == 50 and abs(hist[50] - ref["res50"]) <= 0.0006e-5 + 5e-5 * ref["res50"], hist[50]
     hist_par = hist.copy()
     # (b) exact order: first 3 iterations bit for bit against the oracle on one rank; the parallel sweep within 5e-5 of it
     o = _oracle(256, 256, 32, relax_method="RB")
@@ -159,6 +185,7 @@ def test_config2_rb_256x256x32(mg, golden):
     assert n == no == 3 and _hist_close(hist, ho)
     assert np.array_equal(mg.grid(1).p, o.field("p"))
     assert np.all(np.abs(hist_par[1:4] - ho[1:]) <= 5e-5 * ho[1:])
+    assert np.all(np.abs(hist_seq[1:4] - ho[1:]) <= 1e-13 + 1e-10 * ho[1:]), (hist_seq[1:4], ho[1:])
     assert np.all(np.abs(ho[1:4] - np.array(ref["first5"][:3])) <= 6e-4)
 
 

@@ -28,8 +28,10 @@ def _free_port():
     (2, 2, 32, 32, 16, 8, "FC"),    # BASELINE 64x64x16 on 2x2: 8 neighbours + corners, 2x2 gather at level 4
     (2, 2, 32, 32, 16, 32, "FC"),   # nsmall=32: gathered from level 2 on (every coarse level runs redundantly)
     (4, 1, 16, 32, 8, 16, "FC"),    # 4x1 with nsmall=16: two consecutive gathers (4 -> 2 -> 1 ranks), as bench.py uses for N>1
-    (2, 1, 32, 32, 16, 8, "RB"),    # red-black: parallel semantics, history close to the oracle
-    (2, 2, 32, 32, 16, 32, "RB"),   # red-black on 2x2 with every coarse level gathered
+    (2, 1, 32, 32, 16, 8, "RB"),    # red-black, the default: the reference's sequential order per rank (scan + rank-one correction, mgx_rbseq.hip) to 1e-10
+    (2, 2, 32, 32, 16, 32, "RB"),   # the same on 2x2 with every coarse level gathered
+    (2, 2, 32, 32, 16, 8, "RB+golden"),  # the reference default against its recorded, decomposition-dependent 2x2 history to 1e-10 -- without rb_exact
+    (2, 1, 32, 32, 16, 8, "RB+par"),  # the plain parallel sweep (rb_seq = 0): history within 5e-5 of the oracle
     (2, 1, 64, 128, 64, 8, "FC"),   # nz=64: the level-1 kernels of the bench (matrix-free, 3-deep pipeline) with an open side
     (2, 2, 32, 32, 16, 8, "FC+nop2p"), # the exchange callback (torch.distributed) instead of the peer-to-peer pushes
     (2, 2, 16, 16, 8, 8, "FC+bmask"),  # bmask=.true.: masked coefficients + the 4-D cA halo exchange of define_matrix

@@ -6,8 +6,10 @@ reference's operation order and are compiled without FMA contraction, so their f
 (bit for bit) with the oracle.  Norms are reduced in a different order on the GPU: 1e-13 relative.  Residual
 histories against the ORACLE (same fields, other reduction order): 1e-12 relative; against the reference's RECORDED series
 (tests/golden: another build, its libm): |d| <= 1e-13 + 1e-10*ref in units of ||b|| (north_star: 1e-10 relative).  Red-black ('RB') is order
-dependent in the reference itself; the parallel sweep is checked at the tolerance at which the
-reference agrees with itself across decompositions (1e-5 relative) plus the iteration count."""
+dependent in the reference itself.  The default ("rb_seq") reproduces the reference's sequential order up to
+the association of one sum per column: fields within 1e-12 of the oracle's sequential loop per relax call, histories within
+north_star's 1e-10; "rb_exact" is the same order bit for bit (one launch per plane); the plain parallel sweep (rb_seq = 0) is
+checked at the tolerance at which the reference agrees with itself across decompositions (5e-5 relative)."""
 import numpy as np
 import pytest
 
@@ -152,6 +154,7 @@ def test_relax_rb_chained_snapshot_is_exact(mg):
     # colour passes chain that snapshot themselves (one launch per relax call): must equal a snapshot launch per pass, bit for bit
     nx, ny, nz = 64, 32, 16
     _setup(mg, nx, ny, nz, relax_method="RB")
+    mg.nhydro.set_option("rb_seq", 0)   # the plain parallel sweep is what chains its snapshots
     r = np.random.default_rng(21)
     out = []
     for chain in (1, 0):
@@ -164,6 +167,7 @@ def test_relax_rb_chained_snapshot_is_exact(mg):
             mg.relax(lev, 3)
             out.append(g.get("p"))
     mg.nhydro.set_option("rb_chain", 1)
+    mg.nhydro.set_option("rb_seq", 1)
     assert np.array_equal(out[0], out[2]) and np.array_equal(out[1], out[3])
     assert np.abs(out[0]).max() > 0
 
@@ -178,11 +182,61 @@ def test_relax_rb_real_close(mg):
     p = r.standard_normal(g._shape("p")); b = r.standard_normal(g._shape("b"))
     g.set("p", p); g.set("b", b); mg.fill_halo(1, "p")
     o.field("p")[...] = p; o.field("b")[...] = b; o.fill_halo(1, "p")
-    mg.relax(1, 1)
+    mg.nhydro.set_option("rb_seq", 0)
+    try:
+        mg.relax(1, 1)
+    finally:
+        mg.nhydro.set_option("rb_seq", 1)
     o.relax(1, 1)
     a, c = g.get("p"), o.field("p")
     assert np.abs(a - c).max() <= 0.1 * np.abs(c).max()  # random (rough) fields: the diagonal terms are not small
     assert np.abs(a - c).max() > 0
+    # the same sweep in the sequential order (the default): the rough field's diagonal terms are reproduced, not neglected
+    g.set("p", p); mg.fill_halo(1, "p")
+    mg.relax(1, 1)
+    assert np.abs(g.get("p") - c).max() <= 1e-12 * np.abs(c).max()
+
+
+@pytest.mark.parametrize("dims,geom", [((32, 32, 16), "seamount"), ((64, 32, 16), "rndtopo"), ((16, 128, 8), "seamount"), ((128, 256, 32), "rndtopo"),
+                                       ((256, 512, 8), "seamount"), ((48, 96, 16), "rndtopo"), ((8, 1024, 4), "seamount")])
+def test_relax_rb_sequential_order_at_speed(mg, dims, geom):
+    """relax_method='RB', cmatrix='real' -- the reference default -- in the reference's SEQUENTIAL order (mg_relax.f90:170-186) without
+    a launch per plane (option "rb_seq", the default; mgx_rbseq.hip): parallel colour pass, one-wave walk over the planes for the k=1
+    couplings, rank-one correction per column.  Against the oracle's sequential loop from a rough random state (where the
+    same-colour diagonal terms are large), three sweeps on every level: 1e-12 of max|p| (a few ulp per sweep); every half-row
+    width the walk is instantiated for (partial wave, 1, 2, 4, 8 columns per lane), ragged blocks, both geometries."""
+    nx, ny, nz = dims
+    o = _setup(mg, nx, ny, nz, geom, relax_method="RB")
+    assert mg.nhydro.get_option("rb_seq") == 1
+    rng = np.random.default_rng(31)
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+        g.set("p", p); g.set("b", b); mg.fill_halo(lev, "p")
+        o.field("p", lev)[...] = p; o.field("b", lev)[...] = b; o.fill_halo(lev, "p")
+        mg.relax(lev, 3); o.relax(lev, 3)
+        a, c = g.get("p"), o.field("p", lev)
+        assert np.abs(a - c).max() <= 1e-12 * np.abs(c).max(), (lev, np.abs(a - c).max() / np.abs(c).max())
+
+
+def test_solve_rb_sequential_order_golden(mg, golden):
+    """The reference default on the reference's own recorded run (BASELINE.md 3.1, 64x64x16 on one rank, tol 1e-6): 15 iterations, every
+    residual within 1e-13 + 1e-10*ref, sum(p^2) to 1e-10 -- at north_star's tolerance WITHOUT the per-plane launches of rb_exact."""
+    g = golden["seamount_64x64x16_RB_1rank"]
+    o = _setup(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
+    u, v, w = _uvw(64, 64, 16)
+    mg.nhydro.compute_rhs(u, v, w)
+    n, hist = mg.solve_p(1e-6, 50)
+    ref = np.array(g["res"])
+    assert n == g["nite"] == len(ref)
+    assert np.all(np.abs(hist[1:] - ref) <= 1e-13 + 1e-10 * ref), (hist[1:], ref)
+    p = mg.grid(1).p
+    assert np.isclose((p[1:-1, 1:-1, :] ** 2).sum(), g["sum_p2"], rtol=1e-10)
+    o.field("w")[...] = w
+    o.compute_rhs()
+    no, ho, _ = o.solve_p()
+    assert no == n and np.all(np.abs(hist - ho) <= 1e-13 + 1e-10 * np.abs(ho))
+    assert np.abs(p - o.field("p")).max() <= 1e-10 * np.abs(o.field("p")).max()
 
 
 def test_transfers_bitwise(mg):
@@ -297,7 +351,11 @@ def test_solve_rb_parallel_semantics(mg, golden):
     _setup(mg, 64, 64, 16, relax_method="RB", solver_prec=1e-6)
     u, v, w = _uvw(64, 64, 16)
     mg.nhydro.compute_rhs(u, v, w)
-    n, hist = mg.solve_p(1e-6, 50)
+    mg.nhydro.set_option("rb_seq", 0)   # the plain parallel sweep: old same-colour diagonals everywhere
+    try:
+        n, hist = mg.solve_p(1e-6, 50)
+    finally:
+        mg.nhydro.set_option("rb_seq", 1)
     assert abs(n - g["nite"]) <= 1
     ref = np.array(g["res"])
     m = min(n, len(ref))
