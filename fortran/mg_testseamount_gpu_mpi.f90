@@ -23,7 +23,7 @@ program mg_testseamount_gpu_mpi
        import :: c_int
      end function mgx_rccl_selftest
   end interface
-  integer(kind=4) :: nx, ny, nz, npx, npy, i, j, rc, ierr, myrank, nprocs, pi, pj, use_p2p, use_rccl
+  integer(kind=4) :: nx, ny, nz, npx, npy, i, j, rc, ierr, nprocs, pi, pj, use_p2p, use_rccl   ! myrank: module variable (mg_mpi, through nhydro)
   real(kind=8) :: Lx, Ly, Htot, hc, theta_b, theta_s, x, y, x0, y0, s_loc, s_glo
   real(kind=8), dimension(:,:), pointer :: dx, dy, zeta, h, rmask
   real(kind=8), dimension(:,:,:), allocatable :: u, v, w, p, b
@@ -51,7 +51,6 @@ program mg_testseamount_gpu_mpi
   endif
   pi = mod(myrank, npx); pj = myrank/npx       ! mg_grids.f90:593-594
 
-  nhydro_rank = myrank
   call mgx_check(mgx_mpi_install(MPI_COMM_WORLD), 'mgx_mpi_install')
   if (use_rccl == 1) then
      rc = mgx_mpi_connect_rccl()

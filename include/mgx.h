@@ -176,6 +176,12 @@ int mgx_synchronize(void);
 int mgx_get_option(const char *name, int *value);
 /* print_tictoc (mg_tictoc.f90:114-153): timer table (seconds, calls per level) to `path` (NULL = "fort.10") */
 int mgx_print_tictoc(const char *path);
+/* tic(lev, name) / toc(lev, name) (mg_tictoc.f90:21-111) for the CALLER's own sections -- the reference's drivers bracket their main
+ * program with them (mg_testseamount.f90:37,220).  Host wall clock like the reference's system_clock; toc waits for the solver's stream
+ * first, so that the section contains the GPU work enqueued inside it.  They share the table of mgx_print_tictoc with the library's own
+ * timers (option "tictoc"); the table survives mgx_clean, as the reference's module variables survive nhydro_clean. */
+int mgx_tic(int lev, const char *name);
+int mgx_toc(int lev, const char *name);
 
 /* ---- measurement helpers used by bench.py (timed with HIP events on the solver's stream) ---- */
 /* run `reps` smoother sweeps on level `lev` (reps x relax(lev,1)); *ms = average milliseconds per sweep */

@@ -58,6 +58,8 @@ _SIGS = {
     "mgx_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "mgx_synchronize": (C.c_int, []),
     "mgx_print_tictoc": (C.c_int, [C.c_char_p]),
+    "mgx_tic": (C.c_int, [C.c_int, C.c_char_p]),
+    "mgx_toc": (C.c_int, [C.c_int, C.c_char_p]),
     "mgx_time_relax": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "mgx_selftest_divc": (C.c_int, [_DP, _DP, C.c_int, C.POINTER(C.c_longlong)]),
     "mgx_time_residual": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -32,7 +32,7 @@ int mgxk_relax_ks_persist(hipStream_t, const LevView *, int, int, Sides, unsigne
 int mgxk_set_ksp_timeout(double);
 int mgxk_relax_colour(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);
 int mgxk_relax_small(hipStream_t, const LevView *, int, int, int, Sides, int);
-int mgxk_relax_wave_fused(hipStream_t, const LevView *, const LevView *, int, int, int, Sides, int);
+int mgxk_relax_wave_fused(hipStream_t, const LevView *, const LevView *, int, int, int, Sides, int, int);
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 void mgxk_rbseq_setup(hipStream_t, const LevView *);
@@ -45,6 +45,9 @@ void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *
 void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
+int mgxk_residual_restrict_ex(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero, double *partial, double *dup);
+int mgxk_residual_restrict_grid(const LevView *, const LevView *);
+void mgxk_reduce(hipStream_t, const double *, int, double *);
 void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int, int);
 void mgxk_divc_selftest(hipStream_t, const double *, const double *, int, unsigned long long *);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
@@ -95,6 +98,9 @@ int mgxr_allreduce(hipStream_t, double *, int);
 int mgxr_allgather(hipStream_t, const int *, int, const double *, double *, int);
 }
 
+// a HIP error that was pending when a kernel wrapper started (mgx_before_launch, mgx_device.h): reported by the next synchronising call
+thread_local hipError_t mgx_pending_error = hipSuccess;
+
 namespace {
 
 enum { M_GS = 0, M_RB = 1, M_FC = 2 };
@@ -124,6 +130,7 @@ struct Level {
 };
 
 struct TicRec { int lev, sub; hipEvent_t e0, e1; };
+struct HostTic { int lev, sub; std::chrono::steady_clock::time_point t0; };  // a section the caller opened with mgx_tic
 
 struct State {
   bool inited = false, have_matrix = false;
@@ -171,12 +178,15 @@ struct State {
   int use_fuse = 1;   // option "fuse_tail" / MGX_NO_WAVE_FUSE=1: coarse2fine / residual+restriction folded into the one-workgroup relax of the level below the coarsest (A/B)
   int async_ops = 0;  // option "async": mgx_vcycle / mgx_fcycle / mgx_relax / mgx_fine2coarse / mgx_coarse2fine return without waiting for the stream
   int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
+  int ksp_down = 0;   // the persistent relax kernel timed out in this solver (its workgroups were not all resident): off until the next mgx_init
+  int fuse_closing = 1;  // option "fuse_closing" / MGX_NO_FUSE_CLOSING=1: the closing compute_residual(1) of a solve_p iteration also restricts its r for the next Fcycle, one kernel, no r written (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
   std::string err, transport_name;
   // mg_tictoc.f90's module variables (subname, time, calls, nblev) + the HIP events still in flight
   std::vector<std::string> tt_names;
   std::vector<TicRec> tt_open, tt_done;
+  std::vector<HostTic> tt_host;
   double tt_time[32][32] = {};
   long long tt_calls[32][32] = {};
   int tt_nblev = 0;
@@ -194,6 +204,14 @@ thread_local State *Sp = &S0;
 #define S (*Sp)
 int sync_stream();
 void p2p_release();
+// solvers that hold device state right now: the persistent relax kernel needs all its workgroups resident together, which nothing
+// guarantees once several instances (thread-ranks, coupled domains) put kernels on the same device
+int live_instances() {
+  std::lock_guard<std::mutex> lk(g_instances_mu);
+  int n = 0;
+  for (State *q : g_instances) if (q && q->inited) n++;
+  return n;
+}
 
 int fail(const char *fmt, ...) {
   char buf[512];
@@ -420,12 +438,16 @@ int rl_fill_halo(Level &L, double *a, int nzz, int nh, char c, bool xonly = fals
 // says so, every rank switches the pushes off, rewinds its sequence numbers and flags, and returns the same error: nobody is
 // left pushing to, or waiting for, a rank that fell back alone.
 int global_sum(const Level &L, double *out) {
-  const bool agree = S.nranks > 1 && S.p2p_ready;
+  // The count is the same on every rank of a multi-rank job whatever this rank's transport state (a rank whose hipIpc mapping failed keeps
+  // running on the hooks while its neighbours may have connected: a count chosen from the rank-local p2p_ready would mismatch): always two
+  // values, the second one 0 from a rank without pushes.
+  const bool agree = S.nranks > 1;
   if (S.nranks > 1) {
     if (!S.ar) return fail("an all-reduce is needed (npx*npy > 1) but mgx_set_comm was not called");
     S.n_allred++;
-    if (agree) { mgxk_err_to_double(S.stream, S.p2p_err, S.p2p_failed, S.d_scalar + 1); S.n_launch++; }
-    if (S.ar(S.ctx, S.d_scalar, agree ? 2 : 1)) return fail("allreduce callback failed");
+    if (S.p2p_ready && S.p2p_err) { mgxk_err_to_double(S.stream, S.p2p_err, S.p2p_failed, S.d_scalar + 1); S.n_launch++; }
+    else HIPCHK(hipMemsetAsync(S.d_scalar + 1, 0, sizeof(double), S.stream));
+    if (S.ar(S.ctx, S.d_scalar, 2)) return fail("allreduce callback failed");
   }
   HIPCHK(hipMemcpyAsync(S.h_scalar, S.d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, S.stream));
   CHK(sync_stream());
@@ -433,7 +455,7 @@ int global_sum(const Level &L, double *out) {
     S.p2p_on = false; S.p2p_failed = 0;
     if (S.p2p_err) *S.p2p_err = 0;
     for (auto &Lv : S.lev) { Lv.p2p_seq = 0; Lv.p2p_gseq = 0; }
-    HIPCHK(hipMemsetAsync(S.p2p_flags, 0, 4096 * sizeof(unsigned long long), S.stream));
+    if (S.p2p_flags) HIPCHK(hipMemsetAsync(S.p2p_flags, 0, 4096 * sizeof(unsigned long long), S.stream));
     HIPCHK(hipStreamSynchronize(S.stream));
     return fail("the peer-to-peer halo transport timed out on %d rank(s): ALL ranks have switched to the hooks together (sequence numbers "
                 "rewound); the halos of the affected exchanges were stale, so the current solve is void -- repeat it", (int)S.h_scalar[1]);
@@ -500,10 +522,10 @@ int relax(int lev, int nsweeps) {
   const int exact = S.method == M_RB && S.real && S.rb_exact;
   // sequential-order red-black (mgx_rbseq.hip); the one-workgroup kernels of the small levels run the reference's plane loop itself
   const int seq = S.method == M_RB && S.real && S.rb_seq && !exact && L.v.gk != nullptr;
-  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact || seq)) { S.n_launch++; return 0; }
+  if (S.use_small && nsweeps > 0 && mgxk_relax_small(S.stream, &L.v, nsweeps, S.method, S.real, ph, exact ? 1 : (seq ? 2 : 0))) { S.n_launch++; return 0; }
   const bool closed = all_physical(ph);
   // closed mid levels, four colours: the whole call in one persistent launch, one workgroup per plane (mgx_relax_ks.hip: k_relax_ksp)
-  if (S.method == M_FC && closed && S.use_ksp && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr, S.ksp_test_stall)) {
+  if (S.method == M_FC && closed && S.use_ksp && !S.ksp_down && live_instances() == 1 && mgxk_relax_ks_persist(S.stream, &L.v, nsweeps, S.real, ph, L.ksp_done, L.ksp_seq, S.kerr, S.ksp_test_stall)) {
     S.ksp_test_stall = 0;
     L.ksp_seq += (unsigned int)nsweeps; S.n_launch++;
     return 0;
@@ -533,13 +555,15 @@ int relax(int lev, int nsweeps) {
         L.v.p1w = (L.v.p1 == p1a) ? L.p1b : p1a;
       }
       for (int rb = 1; rb <= 2; rb++) {
-        if (S.real && !chain) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
+        // seq on a closed level: the correction keeps the snapshot current (its colour's new bottom values and their physical images), so one
+        // snapshot launch per relax call; with neighbours the halo part changes with every exchange
+        if (S.real && !chain && !(seq && closed && !(it == 1 && rb == 1))) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
         int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
         if (seq) {
           // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
           if (!mgxk_rbseq_scan(S.stream, &L.v, rb)) return fail("rb_seq: level %d (ny = %d) has no scan instance; set option rb_exact or rb_seq = 0", lev, L.ny);
-          mgxk_rbseq_apply(S.stream, &L.v, rb, ph, 0); S.n_launch += 3;
+          mgxk_rbseq_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0); S.n_launch += 3;
           fused = 1;  // the correction stores the physical images of every column it updates
         }
         CHK(fill_halo_js(L, L.v.p, fused));
@@ -662,11 +686,12 @@ int coarse2fine(int lev, bool keep_r = true, bool skip1 = false) {
 // the fused kernel took the job (same bits as the separate operators), 0 = run them.
 int relax_fused(int lev, int nsweeps, int flags) {
   if (lev >= S.nlevs || !S.use_small || !S.use_fuse || S.method == M_GS || S.tictoc || S.keep_r || S.exact_halos || !S.linear) return 0;
-  if (S.method == M_RB && S.real && (S.rb_exact || S.rb_seq)) return 0;  // sequential-order red-black: the plane loop of k_relax_reg
+  if (S.method == M_RB && S.real && S.rb_exact) return 0;
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
+  const int mode = (S.method == M_RB && S.real && S.rb_seq && F.v.gk != nullptr) ? 2 : 0;
   const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0}, phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0};
   if (!all_physical(phf) || !all_physical(phc) || C.gather) return 0;
-  if (!mgxk_relax_wave_fused(S.stream, &F.v, &C.v, nsweeps, S.method, S.real, phf, flags)) return 0;
+  if (!mgxk_relax_wave_fused(S.stream, &F.v, &C.v, nsweeps, S.method, S.real, phf, flags, mode)) return 0;
   S.n_launch++;
   if (flags & 1) F.r_halo_stale = true;  // what coarse2fine leaves (the correction is not stored in r inside a cycle)
   return 1;
@@ -705,14 +730,43 @@ int vcycle2(int lev1, int lev2) {
 }
 
 // mg_solvers.f90:104-126
-int fcycle() {
+// have_r2: grid(2)%r already holds the restriction of the level-1 residual (the closing compute_residual of the previous solve_p
+// iteration wrote it, residual_closing below): the first fine2coarse is then grid(2)%b = grid(2)%r and grid(2)%p = 0, two small copies
+int fcycle(bool have_r2 = false) {
   TicScope ts(1, "Fcycle");  // mg_solvers.f90:108
   for (int lev = 1; lev <= S.nlevs - 1; lev++) {
+    if (lev == 1 && have_r2) {
+      Level &C = S.lev[1];
+      HIPCHK(hipMemcpyAsync(C.v.b, C.v.r, C.n3js * sizeof(double), hipMemcpyDeviceToDevice, S.stream));   // physical images included (the kernel stored them)
+      HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
+      C.b_halo_stale = true; S.n_launch += 2;
+      continue;
+    }
     CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) CHK(vcycle(lev, true));  // coarse2fine(lev) + Vcycle(lev), :119-120
   return 0;
+}
+
+// compute_residual(1, res) at the end of a solve_p iteration (mg_solvers.f90:65).  If the loop goes on, the next thing that happens to this r
+// is Fcycle's fine2coarse(1) (:112-115): the fused residual+restriction kernel (mgx_resrest.hip) forms the norm's partial sums AND the
+// restricted r in one pass, into grid(2)%r only -- grid(2)%b and %p keep what the last cycle left, should the loop stop here.  The level-1 r
+// is NOT written; the caller materialises it after the loop.  Returns 1 = fused (grid(2)%r is ready), 0 = the caller runs residual(1).
+int residual_closing(double *res) {
+  if (!S.fuse_closing || S.nlevs < 2 || S.exact_halos || S.keep_r || S.tictoc) return 0;
+  Level &F = S.lev[0], &C = S.lev[1];
+  if (C.gather) return 0;
+  const int np = mgxk_residual_restrict_grid(&F.v, &C.v);
+  if (np > S.npartial) return 0;
+  const Sides phc = {C.neighb[0] < 0, C.neighb[1] < 0, C.neighb[2] < 0, C.neighb[3] < 0};
+  if (!mgxk_residual_restrict_ex(S.stream, &F.v, &C.v, C.v.r, S.real, phc, nullptr, S.d_partial, nullptr)) return 0;
+  mgxk_reduce(S.stream, S.d_partial, np, S.d_scalar); S.n_launch += 2;
+  C.r_halo_stale = true;
+  double s;
+  if (global_sum(F, &s)) return -1;
+  *res = sqrt(s);
+  return 1;
 }
 
 // Fortran's Ew.3 edit descriptor (0.dddE+ee), so that the printed history reads like the reference's (format 10, mg_solvers.f90:99)
@@ -749,9 +803,13 @@ int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist
   if (hist) hist[0] = res0;
   FILE *f100 = (S.verbose && S.rank == 0) ? fopen("fort.100", "a") : nullptr;
   if (f100) fprintf(f100, " %24.16E %d\n", res0, nite);
+  bool have_r2 = false;  // grid(2)%r = restriction of the current level-1 residual, and grid(1)%r not written (residual_closing)
   while (nite < maxite && res0 > tol) {
-    CHK(fcycle());
-    CHK(residual(1, &rnorm));
+    CHK(fcycle(have_r2));
+    const int fz = residual_closing(&rnorm);
+    if (fz < 0) return 1;
+    have_r2 = fz == 1;
+    if (!fz) CHK(residual(1, &rnorm));
     rnorm = rnorm / bnorm;
     const double conv = res0 / rnorm;
     res0 = rnorm;
@@ -761,6 +819,7 @@ int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist
     if (f100) fprintf(f100, " %24.16E %24.16E\n", rnorm, conv);
   }
   if (f100) fclose(f100);
+  if (have_r2) CHK(residual(1, nullptr));  // grid(1)%r of the final iterate, which the fused closing residual did not write (once per solve)
   if (S.verbose && S.rank == 0) {  // the summary block (mg_solvers.f90:83-97)
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
     const double np = (double)L.npx * L.npy, ncell = (double)L.nx * L.npx * (double)L.ny * L.npy * (double)L.nz;
@@ -950,13 +1009,18 @@ int sync_stream() {
   HIPCHK(hipStreamSynchronize(S.stream));
   // a kernel launch this thread issued since the last check was refused (launch configuration, LDS or register demand on this
   // device / ROCm): the operator it belonged to did not run, so the fields are not what the caller thinks -- fail loudly
-  { hipError_t le = hipGetLastError(); if (le != hipSuccess) return fail("a kernel launch was rejected: %s", hipGetErrorString(le)); }
+  {
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess && mgx_pending_error != hipSuccess) le = mgx_pending_error;
+    mgx_pending_error = hipSuccess;
+    if (le != hipSuccess) return fail("a HIP call of this thread failed since the last synchronisation (a rejected kernel launch, or an earlier call of the host program): %s", hipGetErrorString(le));
+  }
   if (S.kerr && *S.kerr) {
     // a workgroup of the persistent relax kernel waited 2 s for its neighbour plane: some of its workgroups were kept off the chip
     // (the GPU is shared with kernels that do not finish).  The sweep is incomplete: counters back to zero, the separate launches from now on.
     *S.kerr = 0;
     for (auto &L : S.lev) { if (L.ksp_done) (void)hipMemsetAsync(L.ksp_done, 0, (size_t)(L.nx + 2) * sizeof(unsigned int), S.stream); L.ksp_seq = 0; }
-    S.use_ksp = 0;
+    S.ksp_down = 1;
     return fail("the persistent relax kernel timed out waiting for a neighbouring plane (its workgroups were not all resident); "
                 "the fields of that level are incomplete -- it is now OFF (one launch per colour pair)");
   }
@@ -1226,11 +1290,16 @@ void mgx_clean(void) {
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   if (S.kerr) (void)hipHostFree(S.kerr);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
+  // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
+  std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
+  static thread_local double tsave[32][32]; static thread_local long long csave[32][32];
+  memcpy(tsave, S.tt_time, sizeof tsave); memcpy(csave, S.tt_calls, sizeof csave);
   S = State();
+  S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1318,7 +1387,8 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
       CHK(dmalloc(&L.blk, Ng)); CHK(dmalloc(&L.gbuf, Ng * L.ngroup));
       for (int q = 0; q < 4; q++) CHK(dmalloc(&L.tmp2[q], (size_t)(nyc + 2) * (nxc + 2)));
     }
-    const size_t np = (size_t)mgxk_residual_nblocks(&L.v);
+    size_t np = (size_t)mgxk_residual_nblocks(&L.v);
+    if (l == 1) { const size_t nf = (size_t)mgxk_residual_restrict_grid(&S.lev[0].v, &L.v); if (nf > np) np = nf; }  // the fused closing residual of solve_p
     if (np > max_part) max_part = np;
   }
   S.npartial = (int)max_part;
@@ -1351,6 +1421,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.use_small = getenv("MGX_NO_SMALL") ? 0 : 1;
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
+  if (getenv("MGX_NO_FUSE_CLOSING")) S.fuse_closing = 0;
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
@@ -1527,7 +1598,8 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "rb_seq")) S.rb_seq = value;
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
-  else if (streq(name, "ksp")) S.use_ksp = value;
+  else if (streq(name, "fuse_closing")) S.fuse_closing = value;
+  else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
   else if (streq(name, "fuse_tail")) S.use_fuse = value;
   else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
@@ -1537,6 +1609,9 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "p2p")) {  // collective: every rank switches together, between exchanges
     if (value && !S.p2p_ready) return fail("p2p: mgx_p2p_prepare / mgx_p2p_connect have not been called");
     S.p2p_on = value != 0;
+    // the ranks decide this together (it is collective), so whatever a rank remembered about its own waits is settled here
+    S.p2p_failed = 0;
+    if (S.p2p_err) *S.p2p_err = 0;
   }
   else return fail("unknown option '%s'", name);
   return 0;
@@ -1562,7 +1637,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "rb_seq")) *value = S.rb_seq;
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
-  else if (streq(name, "ksp")) *value = S.use_ksp;
+  else if (streq(name, "fuse_closing")) *value = S.fuse_closing;
+  else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;
   else if (streq(name, "async")) *value = S.async_ops;
   else if (streq(name, "fuse_tail")) *value = S.use_fuse;
   else if (streq(name, "p2p_failed")) *value = S.p2p_failed;
@@ -1592,6 +1668,28 @@ int mgx_print_tictoc(const char *path) {
   }
   fclose(f);
   return 0;
+}
+
+int mgx_tic(int lev, const char *name) {
+  if (lev < 1 || lev > 32 || !name) return fail("tic: level %d outside 1..32", lev);
+  const int sub = tt_sub(name);
+  if (sub >= 32) return fail("tic: more than 32 timer names (mg_tictoc.f90: submax)");
+  S.tt_host.push_back(HostTic{lev, sub, std::chrono::steady_clock::now()});
+  return 0;
+}
+int mgx_toc(int lev, const char *name) {
+  if (lev < 1 || lev > 32 || !name) return fail("toc: level %d outside 1..32", lev);
+  const int sub = tt_sub(name);
+  for (int q = (int)S.tt_host.size() - 1; q >= 0; q--)
+    if (S.tt_host[q].lev == lev && S.tt_host[q].sub == sub) {
+      if (S.inited) (void)hipStreamSynchronize(S.stream);
+      S.tt_time[lev - 1][sub] += std::chrono::duration<double>(std::chrono::steady_clock::now() - S.tt_host[q].t0).count();
+      S.tt_calls[lev - 1][sub]++;
+      if (lev > S.tt_nblev) S.tt_nblev = lev;
+      S.tt_host.erase(S.tt_host.begin() + q);
+      return 0;
+    }
+  return fail("toc(%d,'%s') without a matching tic", lev, name);  // the reference prints "Error: tictoc" and goes on (mg_tictoc.f90:104-108)
 }
 
 // wait for everything enqueued on the solver's stream and report device-side errors (time-outs, rejected launches); the counterpart of option "async"
@@ -1767,6 +1865,8 @@ int mgx_p2p_connect(const void *all_handles, int nranks) {
   if (!S.p2p_slab) return fail("mgx_p2p_connect: call mgx_p2p_prepare first");
   if (nranks != S.nranks) return fail("mgx_p2p_connect: %d handle sets for %d ranks", nranks, S.nranks);
   if ((int)S.lev.size() * 16 > 1024 || (int)S.lev.size() * 8 > 3072) return fail("mgx_p2p_connect: too many levels");
+  // test hook: this rank behaves as if hipIpcOpenMemHandle had refused (a rank that fails alone while its neighbours connect)
+  if (getenv("MGX_P2P_TEST_FAIL_CONNECT") && atoi(getenv("MGX_P2P_TEST_FAIL_CONNECT")) == S.rank) return fail("mgx_p2p_connect: refused on rank %d (test hook MGX_P2P_TEST_FAIL_CONNECT)", S.rank);
   S.peer_slab.assign(nranks, nullptr); S.peer_flags.assign(nranks, nullptr);
   S.peer_slab[S.rank] = S.p2p_slab; S.peer_flags[S.rank] = S.p2p_flags;
   std::vector<char> need(nranks, 0);  // only the ranks that are a neighbour on some level are opened

@@ -33,6 +33,11 @@ __device__ __forceinline__ void mirror_store(const LevView &L, double *__restric
 // A rejected launch (more LDS or registers than this ROCm / device grants) must not pass for a completed colour pass: wrappers that
 // have a generic fallback end in `return mgx_launched();` -- 0 = the launch was refused, nothing ran, the caller falls back; whatever
 // has no fallback is caught by the sticky-error check of the next synchronising call (sync_stream in mgx_api.cpp).
+// hipGetLastError() is sticky per thread for ANY earlier HIP call (an ignored attribute call, the caller's own runtime use): a wrapper that
+// ends in mgx_launched() starts with mgx_before_launch(), which moves whatever is pending into mgx_pending_error (reported by the next
+// synchronising call) so that mgx_launched() sees the status of THIS launch only.
+extern thread_local hipError_t mgx_pending_error;  // mgx_api.cpp
+static inline void mgx_before_launch() { const hipError_t e = hipGetLastError(); if (e != hipSuccess && mgx_pending_error == hipSuccess) mgx_pending_error = e; }
 static inline int mgx_launched() { return hipGetLastError() == hipSuccess ? 1 : 0; }
 
 static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3((ncol_half + WAVE - 1) / WAVE, (nplanes + 3) / 4, z); }
@@ -73,4 +78,18 @@ static inline dim3 col_grid(int ncol_half, int nplanes, int z = 1) { return dim3
 #else
 #define LD_PAIR(ptr, A, B) { A = (ptr)[0]; B = (ptr)[1]; }
 #endif
+
+// the value of the neighbouring lane across the whole wave (DPP wave shifts of gfx9: one v_mov_b32_dpp per half, no LDS)
+__device__ __forceinline__ double wave_shr1(double x) {  // lane n takes lane n-1's value, lane 0 takes 0
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double x) {  // lane n takes lane n+1's value, lane 63 takes 0
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 

@@ -810,6 +810,8 @@ void mgxk_residual(hipStream_t st, const LevView *L, double *partial, double *ou
   else hipLaunchKernelGGL((k_residual<false>), grd, blk, 0, st, *L, partial, want_norm, gx, gy, ph, level_streams(L));
   if (want_norm) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)grd.x, out);
 }
+// second stage of a norm whose partials another kernel wrote (one per workgroup, summed in index order)
+void mgxk_reduce(hipStream_t st, const double *partial, int n, double *out) { hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, n, out); }
 void mgxk_sumsq(hipStream_t st, const LevView *L, const double *a, double *partial, double *out) {
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
   hipLaunchKernelGGL(k_sumsq, grd, blk, 0, st, *L, a, partial);
@@ -927,7 +929,8 @@ static void convert_slots(hipStream_t st, const LevView *L, const Slots8 &o, int
   const size_t lds = (size_t)tj * (L->nz + 1) * sizeof(double);
   // > 64 KB from nz = 64 on; a refusal shows up as a launch error at the next synchronising call (sync_stream)
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_convert_slots, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  // a refused attribute makes the launch below fail, and THAT is reported by the next synchronising call; the attribute call's own status is consumed here
+  if (!attr) { if (hipFuncSetAttribute((const void *)k_convert_slots, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError(); attr = true; }
   hipLaunchKernelGGL(k_convert_slots, dim3((L->ny + 2 + tj - 1) / tj, L->nx + 2, ns), dim3(256), lds, st, *L, o, ref, tj);
 }
 void mgxk_convert8(hipStream_t st, const LevView *L, const double *ref) {

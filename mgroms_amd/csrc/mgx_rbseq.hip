@@ -58,32 +58,26 @@ __global__ void k_rbseq_d0(LevView L, int rb) {
   L.u1[q] = L.p[(long long)i * L.plane + c] - L.p1[q];
 }
 
-__device__ __forceinline__ double wave_shr1(double x) {  // lane n takes lane n-1's value, lane 0 takes 0
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_shl1(double x) {  // lane n takes lane n+1's value, lane 63 takes 0
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
 template <int N> struct VecD { double v[N]; };
 
-// The walk over the planes.  CPL columns per lane; D planes of operands in flight (nx is a multiple of D: the wrapper picks D);
+// The walk over the planes.  NW waves share a half-row, CPL columns per lane (wave w: columns w*64*CPL ...); D planes of operands in
+// flight per wave (nx is a multiple of D: the wrapper picks D);
 // RBP = rb & 1 makes the j parity of a plane a compile-time property of its ring slot (planes start at the odd i = 1, D is even);
-// FULL: the colour's half-row is exactly 64*CPL columns (vector accesses, no lane predicates).
-template <int CPL, int D, int RBP, bool FULL>
-__global__ __launch_bounds__(64) void k_rbseq_scan(LevView L) {
-  const int lane = threadIdx.x, nyh = L.ny >> 1, nx = L.nx;
-  const int jh0 = lane * CPL;
+// FULL: the colour's half-row is exactly NW*64*CPL columns (vector accesses, no lane predicates);
+// D0IN: d0 = p(k=1) - snapshot is formed here (one launch less; a fourth stream) instead of read from u1 (k_rbseq_d0).
+// Memory-level parallelism is what bounds the walk on the large levels: a wave holds at most 63 vector-memory operations in flight
+// (vmcnt), i.e. D * (loads + stores per plane) must stay below that, and every step ends in a scheduling barrier -- without it the
+// compiler sinks all loads of a loop trip behind its last step and the trip waits for a full memory latency (measured: 99 us for the
+// 512 planes of level 1).  With NW > 1 the two values that cross between neighbouring waves go through LDS, one barrier per plane.
+template <int CPL, int D, int RBP, bool FULL, int NW, bool D0IN>
+__global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
+  const int jh0 = (wv * 64 + lane) * CPL;
   const long long RS = L.RS;
   double *__restrict__ u1 = L.u1;
-  const double *__restrict__ g5 = L.ag5, *__restrict__ g8 = L.ag8;
-  VecD<CPL> rd[D], r5[D], r8[D];
+  const double *__restrict__ g5 = L.ag5, *__restrict__ g8 = L.ag8, *__restrict__ p = L.p, *__restrict__ p1 = L.p1;
+  __shared__ double edges[2][NW > 1 ? NW : 1][2];
+  VecD<CPL> rd[D], r5[D], r8[D], ro[D0IN ? D : 1];
   double up[CPL];
   bool ok[CPL];
   int jc[CPL];
@@ -93,37 +87,54 @@ __global__ __launch_bounds__(64) void k_rbseq_scan(LevView L) {
 #define LOADP(ip, slot)                                                                                          \
   {                                                                                                              \
     const int i_ = (ip) <= nx ? (ip) : nx;                                                                       \
-    const long long q_ = (long long)i_ * RS + (((((slot) + 1 + RBP) & 1) == 0) ? L.HO : L.EO + 1);               \
+    const int off_ = (((((slot) + 1 + RBP) & 1) == 0) ? L.HO : L.EO + 1);                                        \
+    const long long q_ = (long long)i_ * RS + off_, qp_ = (long long)i_ * L.plane + off_;                        \
     if (FULL) {                                                                                                  \
-      __builtin_memcpy(&rd[slot], u1 + q_ + jh0, sizeof(VecD<CPL>));                                             \
+      if (D0IN) { __builtin_memcpy(&rd[slot], p + qp_ + jh0, sizeof(VecD<CPL>)); __builtin_memcpy(&ro[D0IN ? (slot) : 0], p1 + q_ + jh0, sizeof(VecD<CPL>)); } \
+      else __builtin_memcpy(&rd[slot], u1 + q_ + jh0, sizeof(VecD<CPL>));                                        \
       __builtin_memcpy(&r5[slot], g5 + q_ + jh0, sizeof(VecD<CPL>));                                             \
       __builtin_memcpy(&r8[slot], g8 + q_ + jh0, sizeof(VecD<CPL>));                                             \
     } else {                                                                                                     \
       _Pragma("unroll") for (int q = 0; q < CPL; q++) {                                                          \
-        rd[slot].v[q] = u1[q_ + jc[q]]; r5[slot].v[q] = g5[q_ + jc[q]]; r8[slot].v[q] = g8[q_ + jc[q]];          \
+        if (D0IN) { rd[slot].v[q] = p[qp_ + jc[q]]; ro[D0IN ? (slot) : 0].v[q] = p1[q_ + jc[q]]; }               \
+        else rd[slot].v[q] = u1[q_ + jc[q]];                                                                     \
+        r5[slot].v[q] = g5[q_ + jc[q]]; r8[slot].v[q] = g8[q_ + jc[q]];                                          \
       }                                                                                                          \
     }                                                                                                            \
   }
+  if (NW > 1) {  // plane 0 is halo: nothing crosses into plane 1
+    if (threadIdx.x < 4 * NW) (&edges[0][0][0])[threadIdx.x] = 0.0;
+    __syncthreads();
+  }
 #pragma unroll
-  for (int d = 0; d < D; d++) LOADP(1 + d, d)
+  for (int d = 0; d < D; d++) { LOADP(1 + d, d) asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }  // slot by slot, as the loop issues them: the waits at the loop head are the minimum of both orders
   for (int i0 = 1; i0 <= nx; i0 += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int i = i0 + d;
-      constexpr int dummy = 0; (void)dummy;
       const bool jodd = (((d + 1 + RBP) & 1) == 0);  // = rb_jodd(i, rb): i0 is odd
       VecD<CPL> un;
       // odd j (position HO + jh):  j+1 <-> previous plane's jh,     j-1 <-> its jh - 1
       // even j (EO + 1 + jh):      j+1 <-> previous plane's jh + 1, j-1 <-> its jh
-      const double edge = jodd ? wave_shr1(up[CPL - 1]) : wave_shl1(up[0]);
+      double edge = jodd ? wave_shr1(up[CPL - 1]) : wave_shl1(up[0]);
+      if (NW > 1) {  // the value that crosses from the neighbouring wave (written at the end of the previous step, before its barrier)
+        const int par = (i - 1) & 1;
+        if (jodd) { const double e = wv > 0 ? edges[par][wv > 0 ? wv - 1 : 0][1] : 0.0; if (lane == 0) edge = e; }
+        else { const double e = wv < NW - 1 ? edges[par][wv < NW - 1 ? wv + 1 : 0][0] : 0.0; if (lane == 63) edge = e; }
+      }
 #pragma unroll
       for (int q = 0; q < CPL; q++) {
         double ua, ub;  // u(j+1,i-1), u(j-1,i-1)
         if (jodd) { ua = up[q]; ub = q > 0 ? up[q > 0 ? q - 1 : 0] : edge; }
         else { ub = up[q]; ua = q < CPL - 1 ? up[q < CPL - 1 ? q + 1 : 0] : edge; }
-        double t = __builtin_fma(-r5[d].v[q], ua, rd[d].v[q]);
+        const double d0 = D0IN ? rd[d].v[q] - ro[D0IN ? d : 0].v[q] : rd[d].v[q];
+        double t = __builtin_fma(-r5[d].v[q], ua, d0);
         t = __builtin_fma(-r8[d].v[q], ub, t);
         un.v[q] = (FULL || ok[q]) ? t : 0.0;
+      }
+      if (NW > 1) {
+        if (lane == 0) edges[i & 1][wv][0] = un.v[0];
+        if (lane == 63) edges[i & 1][wv][1] = un.v[CPL - 1];
       }
       const long long qo = (long long)i * RS + (jodd ? L.HO : L.EO + 1);
       if (FULL) __builtin_memcpy(u1 + qo + jh0, &un, sizeof(VecD<CPL>));
@@ -134,6 +145,8 @@ __global__ __launch_bounds__(64) void k_rbseq_scan(LevView L) {
 #pragma unroll
       for (int q = 0; q < CPL; q++) up[q] = un.v[q];
       LOADP(i + D, d)
+      if (NW > 1) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #undef LOADP
@@ -189,23 +202,33 @@ void mgxk_rbseq_setup(hipStream_t st, const LevView *L) {
 int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
   const int nyh = L->ny / 2, nx = L->nx;
   if (L->gk == nullptr || nyh > 16 * WAVE || (nx & 1)) return 0;
-  hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
+  static const bool one_wave = getenv("MGX_RBSEQ_ONE_WAVE") != nullptr, d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
   const int rbp = rb & 1;
-#define SCAN_CASE(CPLV, DV, FULLV)                                                                                   \
-  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV>), dim3(1), dim3(WAVE), 0, st, *L);                \
-    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV>), dim3(1), dim3(WAVE), 0, st, *L);                    \
+#define SCAN_CASE(CPLV, DV, FULLV, NWV, D0V)                                                                         \
+  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV, NWV, D0V>), dim3(1), dim3(WAVE * NWV), 0, st, *L); \
+    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV, NWV, D0V>), dim3(1), dim3(WAVE * NWV), 0, st, *L);     \
     return 1; }
-  // ring depth: as many planes as the register file takes (3 * CPL * D doubles), a divisor of nx
-#define SCAN_CPL(CPLV, DMAX)                                                                                         \
-  { const bool full = nyh == CPLV * WAVE;                                                                            \
-    if (nx % DMAX == 0) { if (full) SCAN_CASE(CPLV, DMAX, true) else SCAN_CASE(CPLV, DMAX, false) }                 \
-    if (nx % 4 == 0) { if (full) SCAN_CASE(CPLV, 4, true) else SCAN_CASE(CPLV, 4, false) }                          \
-    if (full) SCAN_CASE(CPLV, 2, true) else SCAN_CASE(CPLV, 2, false) }
-  if (nyh <= WAVE) SCAN_CPL(1, 16)
-  if (nyh <= 2 * WAVE) SCAN_CPL(2, 16)
-  if (nyh <= 4 * WAVE) SCAN_CPL(4, 16)
-  if (nyh <= 8 * WAVE) SCAN_CPL(8, 8)
-  SCAN_CPL(16, 4)
+  // ring depth: D * (loads + stores per plane) < 63 (vmcnt), a divisor of nx
+#define SCAN_CPL(CPLV, DMAX, NWV, D0V)                                                                               \
+  { const bool full = nyh == CPLV * WAVE * NWV;                                                                      \
+    if (nx % DMAX == 0) { if (full) SCAN_CASE(CPLV, DMAX, true, NWV, D0V) else SCAN_CASE(CPLV, DMAX, false, NWV, D0V) } \
+    if (nx % 4 == 0) { if (full) SCAN_CASE(CPLV, 4, true, NWV, D0V) else SCAN_CASE(CPLV, 4, false, NWV, D0V) }       \
+    if (full) SCAN_CASE(CPLV, 2, true, NWV, D0V) else SCAN_CASE(CPLV, 2, false, NWV, D0V) }
+  // small half-rows: one wave forms d0 itself (the level lives in L2; the walk is bound by its dependent chain, not by its requests)
+  if (nyh <= 2 * WAVE && !d0_out) {
+    if (nyh <= WAVE) SCAN_CPL(1, 8, 1, true)
+    SCAN_CPL(2, 8, 1, true)
+  }
+  hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
+  if (nyh <= WAVE) SCAN_CPL(1, 16, 1, false)
+  if (nyh <= 2 * WAVE) SCAN_CPL(2, 16, 1, false)
+  // wide half-rows: the requests of ONE wave (at most 63 in flight) do not cover the latency of a level that lives in HBM: several waves
+  if (nyh == 4 * WAVE && !one_wave) SCAN_CPL(2, 16, 2, false)
+  if (nyh == 8 * WAVE && !one_wave) SCAN_CPL(2, 16, 4, false)
+  if (nyh == 16 * WAVE && !one_wave) SCAN_CPL(2, 16, 8, false)
+  if (nyh <= 4 * WAVE) SCAN_CPL(4, 8, 1, false)
+  if (nyh <= 8 * WAVE) SCAN_CPL(8, 4, 1, false)
+  SCAN_CPL(16, 2, 1, false)
 #undef SCAN_CPL
 #undef SCAN_CASE
 }

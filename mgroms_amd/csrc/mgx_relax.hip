@@ -775,8 +775,12 @@ int mgxk_relax_gs_sweep(hipStream_t st, const LevView *L, int real) {
 
 // one-launch relax of a small level; returns 0 if the level does not qualify
 int mgxk_relax_wave(hipStream_t, const LevView *, int, int, int, Sides, int);  // mgx_relax_coarse.hip
-int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
-  if (mgxk_relax_wave(st, L, nsweeps, method, real, ph, exact)) return 1;  // <= 256 columns, nz = 2: the whole level in one wave
+// mode (red-black with cmatrix='real'): 0 = parallel colour passes (snapshot), 1 = the reference's plane loop bit for bit (rb_exact), 2 = the
+// same order by the walk of mgx_rbseq.hip where a kernel has it (k_relax_wave), else the plane loop
+int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode) {
+  mgx_before_launch();
+  if (mgxk_relax_wave(st, L, nsweeps, method, real, ph, mode)) return 1;  // <= 256 columns, nz = 2: the whole level in one wave
+  const int exact = mode != 0;
   {  // one thread per column, coefficients in registers, p in LDS
     static const bool noreg = getenv("MGX_NO_REG") != nullptr;
     const int ncols = L->nx * L->ny;

@@ -23,11 +23,17 @@
 // expressions in the same order as k_coarse2fine, k_residual and k_fine2coarse (the stored diagonal; the matrix-free kernels rebuild
 // the same bits).
 // FZ: the instance that can fold the transfers in (instantiated for nz = 4 only: the plain kernels keep their register budget)
-template <int NZ, bool REAL, int NT, bool FZ = false>
+// SEQ: red-black in the reference's sequential order (the walk below; REAL only) -- its own instances, so that the others keep their registers
+struct VecD4 { double v[4]; };
+template <int NZ, bool REAL, int NT, bool FZ = false, bool SEQ = false>
 __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph, LevView C, int flags) {
+  constexpr bool seq = SEQ && REAL;
   extern __shared__ double ldsw[];
   const int nx = G.nx, ny = G.ny, W = ny, PL = nx * ny;  // P[k][i-1][j-1], interior only
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
+  // seq (the walk below): Q4 = per column the quad {d0 (then s) of the colour in work, cA(5,1), cA(8,1), g(1)} -- one 32-byte read per
+  // plane step -- plus one all-zero quad (index PL) for the lanes past the half-row; GK = g = T^-1 e1 of every column (set once)
+  double *__restrict__ Q4 = ldsw + (NZ + 1) * PL, *__restrict__ GK = Q4 + 4 * (PL + 1);
   const int lane = threadIdx.x;
   // 32-bit element offsets (these levels have a few thousand cells): base pointer in scalar registers + one 32-bit byte offset per load
   // (the 64-bit index arithmetic of ~200 loads per lane and the divisions of a flat cell index were most of this kernel's fixed cost)
@@ -104,6 +110,25 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
       if (REAL) { e2[q] = LD32(G.cA[4], GI(0, j - 1, i + 1)); e4[q] = LD32(G.cA[7], GI(0, j + 1, i + 1)); }
     }
   }
+  // seq (red-black in the reference's sequential order, mgx_rbseq.hip): g = T^-1 e1 of the lane's four columns, by tridiag's recurrences, into LDS
+  if (seq && mine) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int oc = (2 * bi + (q >> 1)) * W + 2 * bj + (q & 1);
+      double gq[NZ];
+      double x = bet[q][0];
+      gq[0] = x;
+#pragma unroll
+      for (int k = 1; k < NZ; k++) { x = (0.0 - a2[q][k] * x) * bet[q][k]; gq[k] = x; }
+#pragma unroll
+      for (int k = NZ - 2; k >= 0; k--) gq[k] = gq[k] - (a2[q][k + 1] * bet[q][k]) * gq[k + 1];
+#pragma unroll
+      for (int k = 0; k < NZ; k++) GK[k * PL + oc] = gq[k];
+      Q4[4 * oc + 1] = a5[q][0]; Q4[4 * oc + 2] = a8[q][0]; Q4[4 * oc + 3] = gq[0];
+    }
+  }
+  if (seq && threadIdx.x < 4) Q4[4 * PL + threadIdx.x] = 0.0;
+  const bool walk_on = REAL && seq && method == 1;
   __syncthreads();
 #define R3(q, k) (((q) & 1) ? xj[(q) >> 1][0][k] : a3[((q) + 1) & 3][k])
 #define R4(q, k) (((q) & 1) ? xj[(q) >> 1][1][k] : a4[((q) + 1) & 3][k])
@@ -150,6 +175,7 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
     /* gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325): the same product as the stored pivot table, recomputed */              \
     _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - (a2[q][k + 1] * bet[q][k]) * x[k + 1];                \
     _Pragma("unroll") for (int k = 0; k < NZ; k++) P[k * PL + oc] = x[k];                                                   \
+    if (walk_on) Q4[4 * oc] = x[0] - P1[oc];   /* d0 of the walk */                                                         \
   }
   for (int it = 0; it < nsweeps; it++) {
     if (method == 2) {  // four colours (mg_relax.f90:212-230): (i odd,j odd), (i odd,j even), (i even,j odd), (i even,j even)
@@ -164,12 +190,68 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
       __syncthreads();
     } else {  // red-black (mg_relax.f90:170-186), parallel semantics: same-colour k=1 diagonals from the snapshot taken before the pass
       const double *__restrict__ Q1 = REAL ? P1 : P;
+      // seq: the reference's plane-after-plane order on top of the parallel pass (header of mgx_rbseq.hip): the walk over the planes finds
+      // u = new - old bottom value of every column of the colour (from plane i-1's u and the two k=1 couplings cA(5), cA(8) of the column;
+      // zero beyond the sides: a halo cell is not refreshed during a colour), then p += g s.  Column q of the lane lies in plane i.
+      // The walk runs on the lanes of wave 0, one lane per column of the colour's half-row, plane after plane with everything in
+      // registers but the operands, which are asked for four planes ahead (one 32-byte LDS read per plane: at most 15 LDS requests
+      // are counted per wave): s = -cA5 u(j+1,i-1) - cA8 u(j-1,i-1), u = d0 + g1 s; the neighbour j-1 / j+1 of the previous plane is the
+      // lane itself and the next lane (a DPP wave shift).  s replaces d0 in the quad.  Lanes past the half-row read the zero quad: u = 0.
+      // Measured (16x16x2, 40 sweeps = 80 colours, box of the pool): parallel passes 55 us per call, + d0 / correction / barriers 86, + the
+      // walk 169; i.e. ~155 cycles per plane step, with the operands one plane ahead (four 8-byte reads, a conditional store) as with four
+      // planes ahead and no branch: ONE wave gets a fraction of the LDS request rate (three LDS operations per step), not its latency.
+      // quad index of the lane's column in plane i; planes past nx and lanes past the half-row: the zero quad (no branch anywhere in the walk)
+#define WALK_OC(i, JODD) ((wact && (i) <= nx) ? ((i) - 1) * W + ((JODD) ? jA : jA + 1) : PL)
+#define WALK_LOAD4(i0_, RBV, R)                                                                                              \
+      { _Pragma("unroll") for (int d_ = 0; d_ < 4; d_++) __builtin_memcpy(&R[d_], Q4 + 4 * WALK_OC((i0_) + d_, ((d_ & 1) == 0) == ((RBV) == 1)), 32); }
+#define WALK_STEP4(i0_, RBV, R)                                                                                              \
+      { _Pragma("unroll") for (int d_ = 0; d_ < 4; d_++) {                                                                    \
+          const bool jo_ = ((d_ & 1) == 0) == ((RBV) == 1);   /* the plane i0_ + d_ holds the colour's odd j (i0_ is odd) */    \
+          const double sh_ = jo_ ? wave_shr1(up) : wave_shl1(up);                                                             \
+          const double ua_ = jo_ ? up : sh_, ub_ = jo_ ? sh_ : up;                                                            \
+          const double s_ = __builtin_fma(-R[d_].v[2], ub_, -(R[d_].v[1] * ua_));                                             \
+          up = __builtin_fma(R[d_].v[3], s_, R[d_].v[0]);                                                                     \
+          Q4[4 * WALK_OC((i0_) + d_, jo_)] = s_;                                                                              \
+        } }
+#define WALK_APPLY(q)                                                                                                        \
+      {                                                                                                                       \
+        const int oc_ = (2 * bi + ((q) >> 1)) * W + 2 * bj + ((q) & 1);                                                       \
+        const double s_ = Q4[4 * oc_];                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < NZ; k++) P[k * PL + oc_] = P[k * PL + oc_] + GK[k * PL + oc_] * s_;              \
+      }
+      // RBV = 1: odd planes hold the colour's odd j (QA = 0), even planes its even j (QB = 3); RBV = 2: the other way round (QA = 1, QB = 2)
+#define SEQ_WALK(QA, QB, RBV)                                                                                                \
+      if (REAL && seq) {                                                                                                      \
+        if (threadIdx.x < 64) {                                                                                               \
+          const bool wact = lane < (ny >> 1);                                                                                 \
+          const int jA = 2 * lane;                                                                                            \
+          double up = 0.0;                                                                                                    \
+          VecD4 ra[4], rb[4];                                                                                                 \
+          WALK_LOAD4(1, RBV, ra)                                                                                              \
+          for (int i0 = 1; i0 <= nx; i0 += 8) {                                                                               \
+            WALK_LOAD4(i0 + 4, RBV, rb)                                                                                       \
+            WALK_STEP4(i0, RBV, ra)                                                                                           \
+            WALK_LOAD4(i0 + 8, RBV, ra)                                                                                       \
+            WALK_STEP4(i0 + 4, RBV, rb)                                                                                       \
+          }                                                                                                                   \
+        }                                                                                                                     \
+        __syncthreads();                                                                                                      \
+        if (mine) { WALK_APPLY(QA) WALK_APPLY(QB) }                                                                           \
+        __syncthreads();                                                                                                      \
+      }
       if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(0) COLUMN(3) }   // rb = 1: j = 1+mod(i+1,2): (i odd, j odd) and (i even, j even)
       __syncthreads();
+      SEQ_WALK(0, 3, 1)
       if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(1) COLUMN(2) }   // rb = 2
       __syncthreads();
+      SEQ_WALK(1, 2, 2)
+#undef SEQ_WALK
+#undef WALK_APPLY
+#undef WALK_STEP4
+#undef WALK_LOAD4
+#undef WALK_OC
     }
   }
   if (FZ && (flags & 2) && mine) {
@@ -249,42 +331,59 @@ extern "C" {
 // eight waves: the 64x32x2 coarsest grid that eight GPUs gather (4x2 ranks of 512x512x64: its 40 sweeps took 436 us in k_relax_small,
 // which re-reads every operand through L2, a fifth of a V-cycle on every rank)
 // Cv, flags: see k_relax_wave (0 / nullptr = the plain relax call); mgxk_relax_wave_fused is the entry the cycles use
-static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact, const LevView *Cv, int flags) {
+// mode (red-black with cmatrix='real' only): 0 = parallel colour passes, 1 = the bit-exact plane loop (not here: k_relax_reg), 2 = the
+// reference's sequential order by the walk (k_relax_wave's seq)
+static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode, const LevView *Cv, int flags) {
+  mgx_before_launch();
   static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr, off8 = getenv("MGX_NO_WAVE8") != nullptr;
-  if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (exact && method == 1 && real)) return 0;
+  if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (mode == 1 && method == 1 && real)) return 0;
+  const int seq = (mode == 2 && method == 1 && real) ? 1 : 0;
+  if (seq && L->ny / 2 > WAVE) return 0;  // the walk keeps a half-row on the lanes of one wave; wider levels: k_relax_reg's plane loop
   const int nblk = (L->nx / 2) * (L->ny / 2);
   if (!(ph.S && ph.E && ph.N && ph.W) || (L->nx & 1) || (L->ny & 1) || nblk > (L->nz == 2 && !off8 ? 8 : 4) * WAVE) return 0;
   if ((nblk > WAVE || L->nz == 4) && off4) return 0;
-  const size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
+  size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
+  if (seq) {  // p, the snapshot and u, interiors only
+    bytes = ((2 * (size_t)L->nz + 5) * L->nx * L->ny + 4) * sizeof(double);  // p, the snapshot, the operand quads (+ a zero quad), g
+    if (bytes > 160 * 1024) return 0;
+  }
   const LevView Cc = Cv ? *Cv : *L;
+#define WAVE_LDS(KERNEL)                                                                                                      \
+  { static size_t granted = 65536;                                                                                               \
+    if (bytes > granted) { if (hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; } granted = 160 * 1024; } }
 #define WAVE_CASE(NZV, NTV)                                                                                                   \
-  { if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);      \
+  { if (seq) { WAVE_LDS((k_relax_wave<NZV, true, NTV, false, true>))                                                           \
+      hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV, false, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); } \
+    else if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); \
     else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);          \
     return mgx_launched(); }
 #define WAVE_CASE_FZ(NTV)                                                                                                     \
-  { if (real) hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);  \
+  { if (seq) { WAVE_LDS((k_relax_wave<4, true, NTV, true, true>))                                                              \
+      hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); } \
+    else if (real) hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); \
     else hipLaunchKernelGGL((k_relax_wave<4, false, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);      \
     return mgx_launched(); }
-  if (flags) {
+  if (flags & 3) {
     if (L->nz != 4) return 0;
     if (nblk <= WAVE) WAVE_CASE_FZ(64) else WAVE_CASE_FZ(256)
   }
   if (L->nz == 2) { if (nblk <= WAVE) WAVE_CASE(2, 64) else if (nblk <= 4 * WAVE) WAVE_CASE(2, 256) else WAVE_CASE(2, 512) }
   if (nblk <= WAVE) WAVE_CASE(4, 64) else WAVE_CASE(4, 256)
 #undef WAVE_CASE_FZ
+#undef WAVE_LDS
 #undef WAVE_CASE
 }
 
-int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int exact) {
-  return relax_wave_launch(st, L, nsweeps, method, real, ph, exact, nullptr, 0);
+int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode) {
+  return relax_wave_launch(st, L, nsweeps, method, real, ph, mode, nullptr, 0);
 }
 // relax(lev, nsweeps) of a closed level the one-workgroup kernel serves, with coarse2fine(lev) folded in front (flags & 1) and / or
 // compute_residual(lev) + fine2coarse(lev) folded behind (flags & 2); C = level lev+1 (closed, exactly half the size, not gathered).
 // Returns 1 when launched, 0 = the caller runs the separate operators.
-int mgxk_relax_wave_fused(hipStream_t st, const LevView *L, const LevView *C, int nsweeps, int method, int real, Sides ph, int flags) {
+int mgxk_relax_wave_fused(hipStream_t st, const LevView *L, const LevView *C, int nsweeps, int method, int real, Sides ph, int flags, int mode) {
   static const bool off = getenv("MGX_NO_WAVE_FUSE") != nullptr;
   if (off || !C || C->nx * 2 != L->nx || C->ny * 2 != L->ny || C->nz * 2 != L->nz || nsweeps < 0) return 0;
-  return relax_wave_launch(st, L, nsweeps, method, real, ph, 0, C, flags);
+  return relax_wave_launch(st, L, nsweeps, method, real, ph, mode, C, flags);
 }
 
 }  // extern "C"

@@ -582,6 +582,7 @@ extern "C" {
 
 // returns 1 when the pass was launched here (the level qualifies), 0 to let the row-by-row kernels take it
 int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
+  mgx_before_launch();
   static const bool off = getenv("MGX_NO_KS") != nullptr, noxcd = getenv("MGX_NO_XCD") != nullptr;
   static const int nw_env = getenv("MGX_KS_NW") ? atoi(getenv("MGX_KS_NW")) : 0;
   static const bool ks8 = getenv("MGX_NO_KS8") == nullptr;
@@ -624,6 +625,7 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
 
 // both colours of the planes i0, i0+2, ... of a four-colour sweep in one launch; returns 1 when launched (closed level, one column set per plane)
 int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, int real, Sides ph) {
+  mgx_before_launch();
   static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr;
   if (off || L->zy == nullptr || !(ph.S && ph.E && ph.N && ph.W) || (L->ny & 1) || L->ny / 2 > WAVE) return 0;
   if (L->nz != 16 && L->nz != 8) return 0;
@@ -643,6 +645,7 @@ int mgxk_set_ksp_timeout(double ms) {
 }
 // stall: test hook, the plane whose workgroup returns at once (0 = none)
 int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int real, Sides ph, unsigned int *done, unsigned int base, int *err, int stall) {
+  mgx_before_launch();
   static const bool off = getenv("MGX_NO_KS") != nullptr || getenv("MGX_NO_KS2") != nullptr || getenv("MGX_NO_KSP") != nullptr;
   // default: plain accesses between agent-scope release / acquire fences (the architecturally guaranteed hand-off); MGX_KSP_SC1=1: the
   // fence-free form with sc1 stores and loads (measured on gfx950 only) -- the two time the same (F-cycle 283-285 vs 285 it/s)
@@ -652,10 +655,24 @@ int mgxk_relax_ks_persist(hipStream_t st, const LevView *L, int nsweeps, int rea
   // nz = 16: four waves of four rows (both colours' coefficients of a lane: 288 registers, one wave per SIMD); nz = 8: eight waves of one row;
   // nz = 4: four waves of one row (the 128x64x4 level that eight GPUs gather; a single GPU's 32x32x4 level is k_relax_wave's)
   dim3 grd(L->nx), blk(WAVE, L->nz == 8 ? 8 : 4);
-#define KSP(NZV, RV, FV) hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 8 ? 8 : 4), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err, stall)
-  if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true); else KSP(16, true, false); } else { if (fence) KSP(16, false, true); else KSP(16, false, false); } }
-  else if (L->nz == 8) { if (real) { if (fence) KSP(8, true, true); else KSP(8, true, false); } else { if (fence) KSP(8, false, true); else KSP(8, false, false); } }
-  else { if (real) { if (fence) KSP(4, true, true); else KSP(4, true, false); } else { if (fence) KSP(4, false, true); else KSP(4, false, false); } }
+  // The workgroups wait for each other: ALL nx of them must be resident together.  The occupancy the runtime reports for this kernel times
+  // the device's compute units must cover the grid (asked once per instance of the template), else the separate launches take the call.
+  static int ncu = 0;
+  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; else { (void)hipGetLastError(); ncu = -1; } }
+#define KSP(NZV, RV, FV)                                                                                                          \
+  {                                                                                                                                \
+    static int cap = -1;                                                                                                           \
+    if (cap < 0) {                                                                                                                 \
+      int nb = 0;                                                                                                                  \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_relax_ksp<NZV, (NZV == 8 ? 8 : 4), RV, FV>, WAVE * (NZV == 8 ? 8 : 4), 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; } \
+      cap = ncu > 0 ? nb * ncu : 0;                                                                                                \
+    }                                                                                                                              \
+    if (cap < (int)grd.x) return 0;                                                                                                \
+    hipLaunchKernelGGL((k_relax_ksp<NZV, (NZV == 8 ? 8 : 4), RV, FV>), grd, blk, 0, st, *L, nsweeps, ph, done, base, err, stall); \
+  }
+  if (L->nz == 16) { if (real) { if (fence) KSP(16, true, true) else KSP(16, true, false) } else { if (fence) KSP(16, false, true) else KSP(16, false, false) } }
+  else if (L->nz == 8) { if (real) { if (fence) KSP(8, true, true) else KSP(8, true, false) } else { if (fence) KSP(8, false, true) else KSP(8, false, false) } }
+  else { if (real) { if (fence) KSP(4, true, true) else KSP(4, true, false) } else { if (fence) KSP(4, false, true) else KSP(4, false, false) } }
 #undef KSP
   return mgx_launched();
 }

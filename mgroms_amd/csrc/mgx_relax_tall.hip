@@ -258,6 +258,7 @@ __global__ __launch_bounds__(128, 1) void k_relax_tall(LevView L, int i0, int is
 // nz = 128 (BASELINE config 5): matrix-free form only, lower 64 rows through memory (relax_col_mf_tall)
 extern "C" int mgxk_relax_nz128(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   if (L->zy == nullptr) return 0;
+  mgx_before_launch();
   static const bool noxcd = getenv("MGX_NO_XCD") != nullptr, notall = getenv("MGX_NO_TALL") != nullptr;
   if (notall) return 0;
   const int gx0 = (L->ny / 2 + WAVE - 1) / WAVE, gx = noxcd ? -gx0 : gx0;

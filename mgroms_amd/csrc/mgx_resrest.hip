@@ -80,15 +80,24 @@ __device__ __forceinline__ void load_r(RowR &r, const LevView &F, const Geo &g, 
 // grid: 1-D, gx j-chunks of 32 coarse columns x gy groups of blockDim.y coarse planes, XCD-aware as k_relax_nz.
 // One wave per SIMD (AW = AR = 1: four window rows + two row buffers, ~450 registers with the requests kept ahead of their use;
 // squeezed to 256 registers for two waves per SIMD it spills and loses: 250 vs 236 us at 512x512x64 in round 2).
-template <bool REAL, int AW, int AR>
-__global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx, int gy) {
+// NORM: also the sum of r^2 over the block's fine cells -> partial[blockIdx.x] (the closing compute_residual of a solve_p iteration,
+// mg_solvers.f90:65, whose r the next Fcycle restricts first thing, :112-115: one pass over the level instead of two and no r written).
+// dup: a second destination of the coarse sums (Fcycle's grid(lev+1)%r = grid(lev+1)%b, :113).
+template <bool REAL, int AW, int AR, bool NORM = false>
+__global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx, int gy,
+                                                             double *__restrict__ partial = nullptr, double *__restrict__ dup = nullptr) {
+  __shared__ double red_ss[4];
+  double ss = 0.0;
   int bx, by;
   if ((gy & 7) == 0) { const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3; by = xcd * (gy >> 3) + local / gx; bx = local - (local / gx) * gx; }
   else { by = blockIdx.x / gx; bx = blockIdx.x - by * gx; }
   const int half = threadIdx.x >> 5;                     // 0: fine plane iA = 2 i2 - 1, 1: iB = 2 i2
   int j2 = 1 + bx * 32 + (threadIdx.x & 31);
   const int i2 = 1 + by * blockDim.y + threadIdx.y;
-  if (i2 > C.nx) return;                                 // wave-uniform
+  if (i2 > C.nx) {                                       // wave-uniform
+    if (NORM) { if ((threadIdx.x & 63) == 0) red_ss[threadIdx.y] = 0.0; __syncthreads(); if (threadIdx.x == 0 && threadIdx.y == 0) partial[blockIdx.x] = red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3]; }
+    return;
+  }
   const bool live = j2 <= C.ny;
   if (!live) j2 = C.ny;                                  // ragged chunk: dead lanes shadow a live column (they take part in the shuffles), store nothing
   const int nz = F.nz;
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
   /* fine2coarse_3D (mg_intergrids.f90:149-160): (k,jA,iA) + (k,jA,iB) + (k,jB,iA) + (k,jB,iB), then the same of k+1;
      the iB values come from the partner lane (lane ^ 32) */
 #define RR_SUM(k, r)                                                                                                        \
+    if (NORM && live) ss = ss + (r[0] * r[0] + r[1] * r[1]);                                                                \
     const double rA_B = __shfl_xor(r[0], 32, 64), rB_B = __shfl_xor(r[1], 32, 64);                                          \
     if ((k) & 1) z = r[0] + rA_B + r[1] + rB_B;                                                                             \
     else {                                                                                                                  \
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
         const long long rc = (long long)(((k) >> 1) - 1) * C.RS;                                                            \
         dst[oc + rc] = z;                                                                                                   \
         mirror_store(C, dst, rc, j2, i2, jpos(C, j2), z, ph);                                                               \
+        if (dup) { dup[oc + rc] = z; mirror_store(C, dup, rc, j2, i2, jpos(C, j2), z, ph); }                                 \
         if (zero) { zero[oc + rc] = 0.0; mirror_store(C, zero, rc, j2, i2, jpos(C, j2), 0.0, ph); }                          \
       }                                                                                                                     \
     }
@@ -221,6 +232,13 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
   }
 #undef RR_STEP
 #undef RR_LOADS
+  if (NORM) {  // wave sum (lanes in index order pairs), then the block's four waves in order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red_ss[threadIdx.y] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) partial[blockIdx.x] = red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3];
+  }
 }
 
 // The same operator without the walk.  A lane that climbs its column pays one memory round trip per row step (20 us for nz = 16 and 13 us
@@ -228,8 +246,10 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
 // coarse columns (both fine planes, as above): the S + 2 window rows and the S rows' own values are all requested at once, the rows are
 // computed and the 8-cell sums closed with the partner lane -- one round trip, nz/S times the waves.  Same expressions (the macros above),
 // same order: bit-identical.
-template <bool REAL, int S>
-__global__ __launch_bounds__(64) void k_residual_restrict_flat(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx) {
+template <bool REAL, int S, bool NORM = false>
+__global__ __launch_bounds__(64) void k_residual_restrict_flat(LevView F, LevView C, double *__restrict__ dst, Sides ph, double *__restrict__ zero, int gx,
+                                                              double *__restrict__ partial = nullptr, double *__restrict__ dup = nullptr) {
+  double ss = 0.0;
   // 1-D grid, k fastest: the nz/S waves of one (plane, j-chunk) share two of their window rows with the wave above and below, so they
   // are kept together in time and on ONE XCD (workgroups are dealt to the eight XCDs round-robin), where that re-use is an L2 hit
   const int nz = F.nz, nks = (nz + S - 1) / S, ng = gx * C.nx;
@@ -299,6 +319,11 @@ __global__ __launch_bounds__(64) void k_residual_restrict_flat(LevView F, LevVie
       RR_SUM(kr, rv)  /* odd row: z = its four values; even row: z += its four values, store coarse row kr/2 */
     }
   }
+  if (NORM) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (threadIdx.x == 0) partial[blockIdx.x] = ss;
+  }
 }
 #undef RR_SUM
 #undef RR_CELL_IN
@@ -308,7 +333,19 @@ __global__ __launch_bounds__(64) void k_residual_restrict_flat(LevView F, LevVie
 extern "C" {
 
 // returns 1 when launched (matrix-free slopes present, level large enough to be bandwidth-bound), 0 = use mgxk_residual + mgxk_fine2coarse
-int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, double *dst, int real, Sides ph, double *zero) {
+// partial != nullptr: also sum r^2 (partials, one per workgroup; *npartial_out = their number); dup: second destination of the coarse sums
+int mgxk_residual_restrict_grid(const LevView *F, const LevView *C) {  // workgroups (= norm partials) of the launch below
+  static const long long flatmax = getenv("MGX_RESREST_FLAT_MAX") ? atoll(getenv("MGX_RESREST_FLAT_MAX")) : 256LL * 256 * 64;
+  const int gx = (C->ny + 31) / 32;
+  if ((long long)F->nx * F->ny * F->nz <= flatmax) {
+    static const int senv = getenv("MGX_RESREST_FLAT_S") ? atoi(getenv("MGX_RESREST_FLAT_S")) : 0;
+    const int Sv = (senv >= 4 && F->nz >= 4) ? 4 : 2;
+    return gx * C->nx * ((F->nz + Sv - 1) / Sv);
+  }
+  return gx * ((C->nx + 3) / 4);
+}
+int mgxk_residual_restrict_ex(hipStream_t st, const LevView *F, const LevView *C, double *dst, int real, Sides ph, double *zero, double *partial, double *dup) {
+  mgx_before_launch();
   static const bool off = getenv("MGX_NO_RESREST") != nullptr;
   static const long long mincells = getenv("MGX_RESREST_MIN") ? atoll(getenv("MGX_RESREST_MIN")) : 0;
   if (off || F->zy == nullptr || F->nz < 2 || (F->nz & 1)) return 0;
@@ -319,17 +356,18 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
     static const int senv = getenv("MGX_RESREST_FLAT_S") ? atoi(getenv("MGX_RESREST_FLAT_S")) : 0;
     const int gx = (C->ny + 31) / 32, Sr = senv ? senv : 2;
     dim3 blk(WAVE);
-#define RRF(REALV, SV) hipLaunchKernelGGL((k_residual_restrict_flat<REALV, SV>), dim3((unsigned)gx * C->nx * ((F->nz + SV - 1) / SV)), blk, 0, st, *F, *C, dst, ph, zero, gx)
-    if (Sr >= 4 && F->nz >= 4) { if (real) RRF(true, 4); else RRF(false, 4); }
-    else { if (real) RRF(true, 2); else RRF(false, 2); }
+#define RRF(REALV, SV, NV) hipLaunchKernelGGL((k_residual_restrict_flat<REALV, SV, NV>), dim3((unsigned)gx * C->nx * ((F->nz + SV - 1) / SV)), blk, 0, st, *F, *C, dst, ph, zero, gx, partial, dup)
+#define RRF2(SV) { if (partial) { if (real) RRF(true, SV, true); else RRF(false, SV, true); } else { if (real) RRF(true, SV, false); else RRF(false, SV, false); } }
+    if (Sr >= 4 && F->nz >= 4) RRF2(4) else RRF2(2)
+#undef RRF2
 #undef RRF
     return mgx_launched();
   }
   const int by = 4, gx = (C->ny + 31) / 32, gy = (C->nx + by - 1) / by;
   dim3 blk(WAVE, by), grd(gx * gy);
   static const int deep = getenv("MGX_RESREST_AHEAD") ? atoi(getenv("MGX_RESREST_AHEAD")) : 11;  // 10 * AW + AR (A/B: scripts/probe/ab_resrest_ahead.sh -- 11, 12, 21 within 5 % of each other once the requests are unconditional)
-#define RRW(REALV, AWV, ARV) hipLaunchKernelGGL((k_residual_restrict<REALV, AWV, ARV>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy)
-#define RRW2(AWV, ARV) { if (real) RRW(true, AWV, ARV); else RRW(false, AWV, ARV); }
+#define RRW(REALV, AWV, ARV, NV) hipLaunchKernelGGL((k_residual_restrict<REALV, AWV, ARV, NV>), grd, blk, 0, st, *F, *C, dst, ph, zero, gx, gy, partial, dup)
+#define RRW2(AWV, ARV) { if (partial) { if (real) RRW(true, AWV, ARV, true); else RRW(false, AWV, ARV, true); } else { if (real) RRW(true, AWV, ARV, false); else RRW(false, AWV, ARV, false); } }
   switch (deep) {
     case 12: RRW2(1, 2) break;
     case 21: RRW2(2, 1) break;
@@ -338,6 +376,9 @@ int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, d
 #undef RRW2
 #undef RRW
   return mgx_launched();
+}
+int mgxk_residual_restrict(hipStream_t st, const LevView *F, const LevView *C, double *dst, int real, Sides ph, double *zero) {
+  return mgxk_residual_restrict_ex(st, F, C, dst, real, ph, zero, nullptr, nullptr);
 }
 
 }  // extern "C"

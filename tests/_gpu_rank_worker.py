@@ -20,6 +20,9 @@ def main():
     par = "par" in opts            # relax_method='RB' as the plain parallel sweep (rb_seq = 0); default: the sequential order at speed (rb_seq = 1)
     golden = "golden" in opts      # namelist defaults, compared with the reference's recorded 2x2 history (tests/golden)
     rndtopo = "rndtopo" in opts    # mg_testrndtopo's geometry (BASELINE config 4) instead of the seamount
+    connectfail = "connectfail" in opts  # rank 1 cannot open its neighbours' buffers (test hook): everybody must end up on the hooks, and every norm's all-reduce must carry the same count on all ranks
+    if connectfail:
+        os.environ["MGX_P2P_TEST_FAIL_CONNECT"] = "1"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ["OMP_NUM_THREADS"] = "1"  # every worker runs the whole emulated-MPI oracle: no OpenMP teams fighting for the cores
     import time
@@ -114,8 +117,12 @@ def main():
         assert np.array_equal(mg.grid(1).r, o.field("r", 1, rank)), rank
     c = nhydro.counters()
     assert c["exchanges"] > 0 and c["allreduces"] > 0  # the set-up halos always use the callback
-    assert (c["p2p_exchanges"] > 0) == p2p
-    if p2p and method == "FC":
+    if connectfail:
+        assert comm.p2p_active is False and comm.p2p_error, (rank, comm.p2p_error)
+        assert c["p2p_exchanges"] == 0
+    else:
+        assert (c["p2p_exchanges"] > 0) == p2p
+    if p2p and method == "FC" and not connectfail:
         # same solve through the other transport (exchange callback): the iterates must not depend on it
         p_first = mg.grid(1).p
         comm.set_p2p(False)

@@ -39,6 +39,7 @@ def _free_port():
     (2, 2, 32, 64, 128, 16, "FC"),  # BASELINE config 5's shape: nz=128 (k_relax_tall with open sides) + gather at level 3 (nsmall=16)
     (2, 2, 32, 32, 16, 8, "RB+exact+golden"),  # reference default in the reference's order: its recorded 2x2 history to 1e-10, p bitwise
     (2, 1, 32, 32, 16, 8, "RB+exact"),  # exact-order red-black with one open side and a 2x1 gather
+    (2, 2, 32, 32, 16, 8, "FC+connectfail"),  # one rank fails to open its peers' buffers: all ranks fall back to the hooks together, the norms' all-reduce keeps one count on every rank
 ])
 def test_multirank_solve(npx, npy, nx, ny, nz, nsmall, method):
     world, port = npx * npy, _free_port()
