@@ -24,6 +24,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 SMOOTHER_BYTES_PER_CELL = 88  # cA 64 + b 8 + p read 8 + p write 8, per cell per full sweep
+VCYCLE_BYTES_PER_CELL = 633   # one Vcycle(1), all levels
+FCYCLE_BYTES_PER_CELL = 812   # one solve_p iteration = Fcycle + the closing residual
+# the reference's own value of `nsmall` for the named multi-GPU configurations: the namelist default 8 (config 4), 16 for config 5
+REFERENCE_NSMALL = {2: 8, 4: 8, 8: 16}
 PGRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 # oracle/mgoracle.c against the real reference (flang -O2 + MPICH) on the SAME 8 cores of the development container, 4x2
 # ranks, seamount 512x512x64: reference time / port time.  Relates the port's number on the
@@ -90,7 +94,9 @@ def main():
     ap.add_argument("--method", default="FC", choices=["FC", "RB"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-reps", type=int, default=20)
-    ap.add_argument("--nsmall", type=int, default=256, help="nsmall used when N>1 (coarse-level agglomeration threshold)")
+    ap.add_argument("--nsmall", type=int, default=256,
+                    help="nsmall of the timed region when N>1 (the reference's coarse-level agglomeration threshold, a namelist member; its default is 8). "
+                         "The rate at the reference's own value for the named configuration is measured as well (also_reference_nsmall)")
     ap.add_argument("--no-p2p", action="store_true", help="N>1: halos through the torch.distributed callback only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
@@ -167,6 +173,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res1 = mg.compute_residual(1)
+    # the same K steps with a host synchronisation after every cycle (how rounds 1 and 2 timed the step): reported beside `value`
+    sync()
+    t0s = time.perf_counter()
+    for _ in range(args.steps):
+        mg.Vcycle(1)
+    sync()
+    dt_sync_each = time.perf_counter() - t0s
+    if world > 1:
+        t = torch.tensor([dt_sync_each], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_sync_each = float(t.item())
 
     # N>1: the peer-to-peer halo transport is only trusted if, on THIS machine, it reproduces the torch.distributed
     # (RCCL) transport bit for bit (four-colour iterates do not depend on who moves the halos); otherwise the timed
@@ -239,25 +256,99 @@ def main():
     mg.grid(1).set("p", p_keep_sp)
 
     counters_main, nlev_main = nhydro.counters(), mg.nlevs()
-    # the reference's default ordering (red-black) on the same workload, for the record (N=1 only)
-    also_rb = None
-    if world == 1 and args.method == "FC":
-        mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
+    # N>1: what one V-cycle exchanges on every rank, and what a level-1 / level-2 halo fill costs there (enqueued back to back, HIP stream time)
+    exchange_report = None
+    if world > 1:
+        c0 = nhydro.counters()
+        mg.Vcycle(1)
+        c1 = nhydro.counters()
+        per_cycle = {k: c1[k] - c0[k] for k in ("halo_fills", "exchanges", "p2p_exchanges", "launches") if k in c0}
+        fill_us = {}
+        nhydro.set_option("async", 1)
+        for lev in (1, 2):
+            if lev > mg.nlevs():
+                continue
+            for _ in range(5):
+                mg.fill_halo(lev, "p")
+            sync()
+            tq = time.perf_counter()
+            for _ in range(50):
+                mg.fill_halo(lev, "p")
+            sync()
+            fill_us[f"level{lev}"] = (time.perf_counter() - tq) / 50 * 1e6
+        nhydro.synchronize()
+        nhydro.set_option("async", 0)
+        mine = {"rank": rank, "per_vcycle": per_cycle, "halo_fill_us": fill_us}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        exchange_report = allr
+    # N>1: the same step at the reference's own nsmall for this configuration (every coarse level distributed; config 5: the 2x2 and 2x1 gathers)
+    also_ref_nsmall = None
+    if world > 1 and args.nsmall != REFERENCE_NSMALL[world]:
+        mg.nhydro_init(nx, ny, nz, npx, npy, rank, nhydro.default_params(relax_method=args.method, nsmall=REFERENCE_NSMALL[world]), comm=comm)
         mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
         nhydro.compute_rhs(u, v, w)
+        nhydro.set_option("async", 1)
         for _ in range(2):
             mg.Vcycle(1)
         sync()
-        t3 = time.perf_counter()
-        nrb = max(5, args.steps // 2)
-        for _ in range(nrb):
+        tr = time.perf_counter()
+        nr = max(5, args.steps // 2)
+        for _ in range(nr):
             mg.Vcycle(1)
         sync()
-        rb_ms = (time.perf_counter() - t3) / nrb * 1e3
-        rb_sweep = nhydro.time_relax(1, args.sweep_reps)
-        also_rb = {"vcycles_per_sec": 1e3 / rb_ms, "ms_per_step": rb_ms, "sweep_ms": rb_sweep,
-                   "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "note": "relax_method='RB' (reference default; parallel red-black semantics, DESIGN.md section 2)"}
+        dtr = time.perf_counter() - tr
+        nhydro.synchronize()
+        nhydro.set_option("async", 0)
+        t = torch.tensor([dtr], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtr = float(t.item())
+        also_ref_nsmall = {"nsmall": REFERENCE_NSMALL[world], "vcycles_per_sec": nr / dtr * npx * npy, "ms_per_step": dtr / nr * 1e3, "levels": mg.nlevs(),
+                           "halo_transport": comm.transport()}
+    # the reference's default ordering (red-black, cmatrix='real') on the same workload (N=1 only), in its three modes: the sequential order at
+    # speed (the default: parallel pass + scan over the planes + rank-one correction, within 1e-10 of the reference's loop), the plain
+    # parallel sweep (5e-5 away) and -- one sweep, once -- the bit-exact order with a launch per plane
+    also_rb = None
+    if world == 1 and args.method == "FC":
+        also_rb = {"note": "relax_method='RB', cmatrix='real' (the reference default, BASELINE config 2's ordering) on the bench's workload"}
+        for mode, opts, tol in (("sequential_order", {"rb_seq": 1, "rb_exact": 0}, "history and p within 1e-10 of the reference's sequential loop (a few ulp per sweep; tests: 1e-12 per relax call)"),
+                                ("parallel", {"rb_seq": 0, "rb_exact": 0}, "history within 5e-5 relative, same iteration counts (old same-colour k=1 diagonals everywhere)")):
+            for k, val in opts.items():
+                nhydro.set_option(k, val)
+            mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
+            mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+            nhydro.compute_rhs(u, v, w)
+            nhydro.set_option("async", 1)
+            for _ in range(2):
+                mg.Vcycle(1)
+            sync()
+            t3 = time.perf_counter()
+            nrb = max(5, args.steps // 2)
+            for _ in range(nrb):
+                mg.Vcycle(1)
+            sync()
+            rb_ms = (time.perf_counter() - t3) / nrb * 1e3
+            nhydro.synchronize()
+            nhydro.set_option("async", 0)
+            rb_sweep = nhydro.time_relax(1, args.sweep_reps)
+            sync()
+            t4 = time.perf_counter()
+            nit_rb = 5
+            nhydro.set_option("warm_start", 1)
+            mg.solve_p(1e-300, nit_rb)
+            sync()
+            rb_it_ms = (time.perf_counter() - t4) / nit_rb * 1e3
+            nhydro.set_option("warm_start", 0)
+            also_rb[mode] = {"vcycles_per_sec": 1e3 / rb_ms, "ms_per_step": rb_ms, "sweep_ms": rb_sweep, "solve_p_iteration_ms": rb_it_ms,
+                             "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, "tolerance": tol}
+        nhydro.set_option("rb_exact", 1)
+        mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
+        mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+        nhydro.compute_rhs(u, v, w)
+        nhydro.time_relax(1, 1)
+        also_rb["exact_order"] = {"sweep_ms": nhydro.time_relax(1, 1), "tolerance": "bit-identical to the reference's sequential loop (one launch per plane: a parity mode)"}
+        nhydro.set_option("rb_exact", 0); nhydro.set_option("rb_seq", 1)
+        also_rb["sweep_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["sweep_ms"] / also_rb["parallel"]["sweep_ms"]
 
     # HBM traffic of the dominant kernel from the PMC counters: they cannot be collected inside this run (rocprofv3 must wrap
     # the process, in passes of their own), so the figure is read from the committed capture of THIS command
@@ -285,12 +376,22 @@ def main():
             "metric": "V-cycles/sec, seamount 512x512x64 (fine-grid smoother HBM GB/s and % of 8 TB/s: see roofline)",
             "value": args.steps / dt * scale, "unit": "V-cycles/s (x number of 512x512x64 blocks when N>1: weak scaling)",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "enqueue": "async (the K steps are enqueued back to back; the region closes with barrier + synchronize)",
+            "value_sync_each_step": args.steps / dt_sync_each * scale, "ms_per_step_sync_each_step": dt_sync_each / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"seamount {nx * npx}x{ny * npy}x{nz} ({npx}x{npy} ranks of {nx}x{ny}x{nz}), "
                                    f"relax_method={args.method}, ns_pre=3 ns_post=2 ns_coarsest=40, cmatrix=real, interp=linear",
                        "levels": nlev_main, "step": "one Vcycle(1)", "halo_transport": transport,
                        "native_rccl": (None if comm is None else (True if comm.native_active else f"off: {comm.native_error}")),
-                       "transport_check": transport_check, "nsmall": (8 if world == 1 else args.nsmall)},
+                       "transport_check": transport_check, "nsmall": (8 if world == 1 else args.nsmall),
+                       "nsmall_note": (None if world == 1 else f"timed region: nsmall={args.nsmall} (coarse levels agglomerated early; a namelist member of the reference, "
+                                       f"default 8); the reference's own value for this configuration, {REFERENCE_NSMALL[world]}, is timed in also_reference_nsmall")},
+            "vcycle_roofline": {"bytes_per_cell": VCYCLE_BYTES_PER_CELL, "ms": dt / args.steps * 1e3,
+                                "frac": VCYCLE_BYTES_PER_CELL * cells / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+            # what solve_p iterates: one F-cycle + the closing residual norm (mg_solvers.f90:61-68), through solve_p itself
+            "fcycle_roofline": {"bytes_per_cell": FCYCLE_BYTES_PER_CELL, "ms": 1e3 / sp_rate, "frac": FCYCLE_BYTES_PER_CELL * cells * sp_rate / 1e9 / HBM_PEAK_GBS,
+                                "unit": "one solve_p iteration (Fcycle + closing residual norm), SURVEY 8(d): 812 B per fine cell"},
+            "exchanges": exchange_report, "also_reference_nsmall": also_ref_nsmall,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # two labelled rates: effective = algorithmic bytes / time (= achieved, the contract's figure); measured = counter

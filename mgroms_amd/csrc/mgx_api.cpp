@@ -1540,7 +1540,7 @@ int mgx_fill_halo(int lev, int field) {
     case MGX_ZW: CHK(rl_fill_halo(L, L.g.zw, L.nz + 1, 2, 0)); break;
     default: return fail("fill_halo: field %d has no halo rule (p, b, r, cA, dx, dy, zeta, h, zr, zw)", field);
   }
-  CHK(sync_stream());
+  CHK(op_sync());  // option "async": enqueued only, like the cycles
   return 0;
 }
 

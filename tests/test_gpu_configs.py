@@ -312,7 +312,9 @@ def test_in_kernel_coefficients_match_stored_slots_on_stretched_grids(mg, dims, 
         n, hist = mg.solve_p(1e-12, 3)
         out.append((hist.copy(), mg.grid(1).p))
     monkeypatch.delenv("MGX_NO_MF", raising=False)
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # the fields bit for bit; the norms to 1e-13: with the stored coefficients the closing residual of an iteration is the plain kernel, with the
+    # in-kernel ones it is fused with the next restriction (mgx_resrest.hip) and sums its partials in another order
+    assert np.array_equal(out[0][1], out[1][1]) and np.all(np.abs(out[0][0] - out[1][0]) <= 1e-13 * out[1][0])
     assert np.abs(out[0][1]).max() > 0 and out[0][0][3] < out[0][0][0]
 
 
