@@ -29,24 +29,7 @@ python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_solve/*/*_kernel_trace.c
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_fetch -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_write -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_write.log 2>&1 || exit 1
 python3 $ROOT/scripts/pmc_summary.py $(ls $OUT/${R}_pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${R}_pmc_write/*/*_counter_collection.csv | head -1) 16777216 > $ROOT/profiles/${R}_pmc_traffic.json || exit 1
-# 5. the reference's timer table (mg_tictoc format) of a 5-iteration solve
-cd $OUT && MGX_TICTOC=1 timeout -k 10 120 python3 - > $OUT/${R}_tictoc.log 2>&1 <<PY
-import sys
-sys.path.insert(0, "$ROOT")
-import numpy as np, torch
-import mgroms_amd as mg
-from mgroms_amd import nhydro
-from mgroms_amd.testcases import seamount_geometry, resting_column_state
-torch.cuda.set_device(0)
-nhydro.set_verbose(0)
-mg.nhydro_init(512, 512, 64, 1, 1, 0, nhydro.default_params(relax_method="FC"))
-mg.nhydro_matrices(*seamount_geometry(512, 512), None, 4e3, 0.0, 0.0)
-nhydro.compute_rhs(*resting_column_state(512, 512, 64))
-mg.solve_p(1e-12, 1)
-nhydro.set_option("tictoc", 1)
-mg.solve_p(1e-12, 5)
-nhydro.print_tictoc("$ROOT/profiles/${R}_tictoc_512x512x64_FC_5it.txt")
-mg.nhydro_clean()
-PY
+# 5. the reference's timer table (mg_tictoc format) of a 5-iteration solve, after an untimed warm-up (scripts/tictoc_table.py)
+timeout -k 10 120 python3 $ROOT/scripts/tictoc_table.py $ROOT/profiles/${R}_tictoc_512x512x64_FC_5it.txt FC > $OUT/${R}_tictoc.log 2>&1 || exit 1
 mkdir -p $OUT/profiles_${R} && cp $ROOT/profiles/${R}_* $OUT/profiles_${R}/
 ls -la $OUT/profiles_${R}/
