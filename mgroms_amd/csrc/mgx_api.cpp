@@ -179,6 +179,15 @@ struct State {
   int async_ops = 0;  // option "async": mgx_vcycle / mgx_fcycle / mgx_relax / mgx_fine2coarse / mgx_coarse2fine return without waiting for the stream
   int use_ksp = 1;    // option "ksp" / MGX_NO_KSP=1: one launch per colour pair instead of the persistent relax kernel (A/B)
   int ksp_down = 0;   // the persistent relax kernel timed out in this solver (its workgroups were not all resident): off until the next mgx_init
+  // halo exchange beside the interior sweep (relax(), four colours on a level with neighbours, pushes on): a second stream carries the
+  // boundary part of a colour pass and the exchange behind it while the solver's stream sweeps the interior
+  hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_s = nullptr, ev_x = nullptr;
+  // OFF by default.  Measured (profiles/r04_overlap_2ranks.txt: two ranks of 512x512x64 sharing the one GPU of a test box): 8.4 ms per V-cycle with
+  // it, 4.7 ms without.  A colour pass of such a block is ONE 512-register wave per SIMD for its whole duration: an exchange wave (or the boundary
+  // part's) on a SIMD keeps the interior part's wave off it, and the boundary part alone takes as long as a whole pass (every wave runs the full
+  // ~50 us), so the chain exchange -> boundary part -> exchange is no shorter than the serial one; the two cross-stream waits per colour come on top.
+  int overlap = 0;       // option "overlap" / MGX_OVERLAP=1 (the same bits either way)
+  long long n_overlap = 0;  // colour passes run that way
   int fuse_closing = 1;  // option "fuse_closing" / MGX_NO_FUSE_CLOSING=1: the closing compute_residual(1) of a solve_p iteration also restricts its r for the next Fcycle, one kernel, no r written (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -570,13 +579,36 @@ int relax(int lev, int nsweeps) {
       }
       if (chain) { L.v.p1 = L.v.p1w; L.v.p1w = nullptr; if (it == nsweeps) L.v.p1 = p1a; }
     } else {
+      // A level with neighbours, halos by the pushes: the boundary part of a colour (the waves that hold a column next to a neighbour's
+      // halo -- what the exchange sends, and all that reads what the last exchange delivered) and the exchange behind it go to a second
+      // stream; the interior part runs beside them on the solver's stream and waits only for the previous colour's boundary part
+      // (mg_relax.f90:181,224 exchange after every colour; SURVEY 7 "split boundary columns from interior, exchange while the interior runs").
+      const bool ov = S.overlap && S.p2p_on && S.stream2 && !closed && mgxk_has_reg_kernel(&L.v);
       for (int fc1 = 1; fc1 <= 2; fc1++) {
         // closed mid levels: the two colours of a plane set in one launch (mgx_relax_ks.hip)
         if (closed && mgxk_relax_ks_pair(S.stream, &L.v, fc1, L.nx / 2, S.real, ph)) { S.n_launch++; continue; }
         for (int fc2 = 1; fc2 <= 2; fc2++) {
+          if (ov) {
+            Sides ps = ph;
+            HIPCHK(hipEventRecord(S.ev_a, S.stream));                 // the interior of the previous colour (and whatever came before)
+            HIPCHK(hipStreamWaitEvent(S.stream2, S.ev_a, 0));
+            ps.part = 1;
+            const int fused = mgxk_relax_colour(S.stream2, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0, ps);
+            HIPCHK(hipEventRecord(S.ev_s, S.stream2));
+            { hipStream_t keep = S.stream; S.stream = S.stream2; const int rc = fill_halo_js(L, L.v.p, fused); S.stream = keep; if (rc) return rc; }
+            ps.part = 2;
+            mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0, ps);
+            HIPCHK(hipStreamWaitEvent(S.stream, S.ev_s, 0));          // what follows on the solver's stream reads this colour's boundary part -- not its exchange
+            S.n_launch += 2; S.n_overlap++;
+            continue;
+          }
           const int fused = mgxk_relax_colour(S.stream, &L.v, 1 + (fc1 - 1) % 2, 2, L.nx / 2, fc2 == 1 ? 1 : 0, 0, S.real, 0, ph); S.n_launch++;
           CHK(fill_halo_js(L, L.v.p, fused));
         }
+      }
+      if (ov && it == nsweeps) {  // the call ends: the solver's stream continues behind the last exchange
+        HIPCHK(hipEventRecord(S.ev_x, S.stream2));
+        HIPCHK(hipStreamWaitEvent(S.stream, S.ev_x, 0));
       }
     }
   }
@@ -1289,8 +1321,12 @@ void mgx_clean(void) {
   for (void *q : S.allocs) (void)hipFree(q);
   if (S.h_scalar) (void)hipHostFree(S.h_scalar);
   if (S.kerr) (void)hipHostFree(S.kerr);
+  if (S.stream2) { (void)hipStreamSynchronize(S.stream2); (void)hipStreamDestroy(S.stream2); }
+  if (S.ev_a) (void)hipEventDestroy(S.ev_a);
+  if (S.ev_s) (void)hipEventDestroy(S.ev_s);
+  if (S.ev_x) (void)hipEventDestroy(S.ev_x);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
   std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
@@ -1299,7 +1335,7 @@ void mgx_clean(void) {
   S = State();
   S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1397,6 +1433,10 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   HIPCHK(hipHostMalloc((void **)&S.h_scalar, 8 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&S.kerr, 64, hipHostMallocMapped));
   *S.kerr = 0;
+  if (S.nranks > 1) {
+    HIPCHK(hipStreamCreateWithFlags(&S.stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&S.ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.ev_s, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.ev_x, hipEventDisableTiming));
+  }
   Level &L1 = S.lev[0];
   S.ref_scratch_n = (size_t)8 * L1.nz * (L1.ny + 2) * (L1.nx + 2);
   CHK(dmalloc(&S.ref_scratch, S.ref_scratch_n));
@@ -1422,6 +1462,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
   if (getenv("MGX_NO_FUSE_CLOSING")) S.fuse_closing = 0;
+  if (getenv("MGX_OVERLAP")) S.overlap = atoi(getenv("MGX_OVERLAP"));
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
   if (getenv("MGX_EXACT_HALOS")) S.exact_halos = 1;
@@ -1599,6 +1640,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "fuse_closing")) S.fuse_closing = value;
+  else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
   else if (streq(name, "fuse_tail")) S.use_fuse = value;
@@ -1638,6 +1680,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "fuse_closing")) *value = S.fuse_closing;
+  else if (streq(name, "overlap")) *value = S.overlap;
+  else if (streq(name, "overlapped_passes")) *value = (int)S.n_overlap;
   else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;
   else if (streq(name, "async")) *value = S.async_ops;
   else if (streq(name, "fuse_tail")) *value = S.use_fuse;

@@ -56,4 +56,13 @@ struct GeoView {
 };
 
 // physical-boundary flags of a sub-domain (1 = no neighbour on that side)
-struct Sides { int S, E, N, W; };
+// part (colour passes of a level with neighbours, mgx_api.cpp relax()): 0 = every column of the colour; 1 = only the waves that hold a
+// column next to a NEIGHBOUR's halo (plane 1 / nx, first / last j-chunk on an open side): the columns the next exchange sends and the only
+// ones that read what the last exchange delivered; 2 = all the others.  The two parts run on two streams, the exchange behind part 1.
+struct Sides { int S, E, N, W; int part; };
+// does the wave of plane i, j-chunk bx (of gx), j parity jodd belong to the part asked for?
+__host__ __device__ inline bool sides_part_skip(const Sides &ph, int i, int nx, int jodd, int bx, int gx) {
+  if (!ph.part) return false;
+  const bool edge = (!ph.W && i == 1) || (!ph.E && i == nx) || (!ph.S && jodd && bx == 0) || (!ph.N && !jodd && bx == gx - 1);
+  return edge != (ph.part == 1);
+}

@@ -152,6 +152,12 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
 #undef LOADP
 }
 
+// Measured and dropped (round 4): the walk with LOADER waves -- eight waves keep four chunks of requests in flight each, form d0 on the way
+// and hand a plane's three operands to ONE walking wave through a double-buffered LDS ring, a workgroup barrier per chunk of eight planes; the
+// walking wave issues no global load at all.  It lost on every level (level 1: 124 us against 73 + 5, level 2: 28 against 21, levels 3 / 4:
+// 11.8 / 8.5 against 10.8 / 7.5): a single wave gets a fraction of the LDS request rate (~50 cycles per request, as in k_relax_wave's walk), and
+// six 16-byte LDS reads per plane cost more than the six global loads they replace (profiles/r04_rbseq_ring_negative.txt).
+
 // (c): p(:,j,i) += g(:,j,i) * s(j,i) for the columns of colour rb, with the physical mirrors (the pass wrote y into them), and -- SNAPW --
 // the new bottom value into the snapshot p1 (and its mirrors), so that a closed level needs no snapshot launch before the next pass.
 // One wave = 64 columns of a plane x the rows [kz*KR, (kz+1)*KR).

@@ -17,13 +17,14 @@
 // The tridiagonal pivots (bet, gam) depend on the matrix only and are precomputed at set-up.
 // ------------------------------------------------------------------------------------------------
 template <bool REAL, bool SNAP>
-__global__ __launch_bounds__(256) void k_relax_colour(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb) {
+__global__ __launch_bounds__(256) void k_relax_colour(LevView L, int i0, int istep, int nplanes, int jodd_fixed, int rb, Sides ph) {
   const int jh = blockIdx.x * WAVE + threadIdx.x;
   const int ipl = blockIdx.y * blockDim.y + threadIdx.y;
   if (jh >= (L.ny >> 1) || ipl >= nplanes) return;
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  if (sides_part_skip(ph, i, L.nx, jodd, blockIdx.x, gridDim.x)) return;
   int c, jm, jp;  // positions of columns j, j-1, j+1 inside a row
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
   else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(128, 1) void k_relax_nz(LevView L, int i0, int iste
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  if (sides_part_skip(ph, i, L.nx, jodd, bx, gx)) return;  // wave-uniform
   constexpr bool GL = MF && NZ == 64 && MGX_GL;  // keep in step with launch_relax_nz_d
   constexpr bool ZW = MF && NZ >= 32 && MGX_ZW;
   if (GL) {
@@ -852,9 +854,9 @@ int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int n
     default: break;
   }
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, nplanes);
-  if (real && snap) hipLaunchKernelGGL((k_relax_colour<true, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
-  else if (real) hipLaunchKernelGGL((k_relax_colour<true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
-  else hipLaunchKernelGGL((k_relax_colour<false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb);
+  if (real && snap) hipLaunchKernelGGL((k_relax_colour<true, true>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else if (real) hipLaunchKernelGGL((k_relax_colour<true, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
+  else hipLaunchKernelGGL((k_relax_colour<false, false>), grd, blk, 0, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph);
   return 0;
 }
 // does mgxk_relax_colour run a register-resident kernel (which writes mirrors and chained snapshots) on this level?

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  if (sides_part_skip(ph, i, L.nx, jodd, bx, gx)) return;  // workgroup-uniform (before any barrier)
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
   else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(128, 1) void k_relax_tall(LevView L, int i0, int is
   const int i = i0 + istep * ipl;
   // RB: j = 1+mod(i+rb,2),ny,2 (mg_relax.f90:174) ; FC: fixed parity (:216-217)
   const int jodd = jodd_fixed >= 0 ? jodd_fixed : (((i + rb) & 1) == 0);
+  if (sides_part_skip(ph, i, L.nx, jodd, bx, gx)) return;  // wave-uniform
   extern __shared__ double xf_lds[];  // blockDim.y waves x LOW rows x 64 lanes
   relax_col_mf_tall<NZ, LOW, REAL, SNAP, D, ST>(L, i, jh, jodd, ph, xf_lds + (size_t)threadIdx.y * LOW * WAVE);
 }

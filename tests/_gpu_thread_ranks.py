@@ -132,7 +132,7 @@ def main():
     # One hardware queue per rank.  The HIP runtime multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues
     # (default 4): two ranks whose streams share a queue are serialised, and a halo kernel that waits for its neighbour's push would sit
     # in front of the very kernel that pushes.  (Process-per-rank runs have a queue set each.)  Must be set before HIP initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * world)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 3 * world)))  # each rank drives two streams (the exchange runs beside the interior sweep)
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("MGX_TEST_WATCHDOG", "100")), exit=True)  # a stuck collective: all stacks, then exit
     import torch
