@@ -159,11 +159,21 @@ int mgx_set_verbose(int level);
  * "c2f_skip" (default 1; MGX_C2F_NOSKIP=1 = 0): inside a cycle the prolongation before a four-colour relax does not update the
  * (i odd, j odd) columns, which that relax's first colour overwrites without reading them (mg_relax.f90:212-216) -- the coupling is
  * asserted by tests/test_gpu_parity.py::test_c2f_skip_is_invisible; 0 updates every column as the reference does;
- * "rb_exact" (default 0; environment MGX_RB_EXACT): relax_method='RB' with cmatrix='real' in the reference's SEQUENTIAL
- * order (mg_relax.f90:170-186: a column reads the same-colour k=1 diagonals of plane i-1 already updated, :271-276), one
- * launch per i-plane -- bit-identical to the reference loop, including its decomposition dependence, but launch-bound.
- * With 0 the colour pass is parallel and reads those four values as they were before the pass (the reference's own
- * results differ by 2.5e-6 between decompositions for the same reason; tolerance in DESIGN.md section 2). */
+ * Red-black with cmatrix='real' (the reference default) depends on the reference's SEQUENTIAL loop order (mg_relax.f90:170-186: a column
+ * reads the same-colour k=1 diagonals of plane i-1 already updated, :271-276).  Three modes:
+ * "rb_seq" (default 1; environment MGX_RB_SEQ): that order at speed -- parallel colour pass, a walk over the planes for the k=1 couplings,
+ *   a rank-one correction per column (mgx_rbseq.hip): the reference's iterates up to the association of one sum per column (tests: 1e-12
+ *   per relax call, histories within 1e-10), including the decomposition dependence on several ranks;
+ * "rb_exact" (default 0; MGX_RB_EXACT): the same order bit for bit, one launch per i-plane (a parity mode, ~90 times slower);
+ * both 0: the plain parallel sweep, same-colour diagonals as they were before the pass (the reference's own results differ by 2.5e-6
+ *   between decompositions for the same reason; 5e-5 on the history).
+ * "fuse_closing" (default 1; MGX_NO_FUSE_CLOSING): inside solve_p the closing compute_residual(1) of an iteration also restricts its r
+ *   for the next Fcycle in the same pass (into grid(2)%r; grid(1)%r is materialised once, after the loop); 0 = the two operators.
+ * "overlap" (default 0; MGX_OVERLAP=1): four colours on a level with neighbours, halos by the pushes: the boundary part of a colour pass and
+ *   the exchange on a second stream beside the interior part.  Same bits; slower where it could be measured.
+ * "ksp" (default 1): the persistent relax of the closed mid levels; read back 0 after it timed out (then off until mgx_init or "ksp" = 1).
+ * Read-only through mgx_get_option: "p2p_failed" (a peer-to-peer wait of THIS rank timed out since the ranks last agreed: see below),
+ *   "overlapped_passes". */
 int mgx_set_option(const char *name, int value);
 /* Option "async" (default 0): the cycle / operator entry points (mgx_vcycle, mgx_vcycle2, mgx_fcycle, mgx_relax, mgx_fine2coarse,
  * mgx_coarse2fine) only ENQUEUE their kernels on the solver's stream and return -- what a GPU-resident model wants between its own

@@ -1393,10 +1393,10 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int q = 0; q < 2; q++) CHK(dmalloc(&L.zg_store[q], (size_t)(L.nx + 2) * L.v.RS));
     for (int q = 2; q < 4; q++) CHK(dmalloc(&L.zg_store[q], (size_t)L.nz + 1));
     L.v.dx2 = L.v.dy2 = nullptr; L.v.cffr = L.v.csr = nullptr;
-    L.v.gk = L.v.ag5 = L.v.ag8 = L.v.u1 = nullptr;
+    L.v.gk = L.v.ag58 = L.v.u1 = nullptr;
     if (S.method == M_RB && S.real) {  // sequential-order red-black (mgx_rbseq.hip): +8 B per cell
       CHK(dmalloc(&L.v.gk, L.n3js));
-      CHK(dmalloc(&L.v.ag5, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.ag8, (size_t)(L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
+      CHK(dmalloc(&L.v.ag58, (size_t)2 * (L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
     }
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;

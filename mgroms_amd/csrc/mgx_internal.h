@@ -32,10 +32,10 @@ struct LevView {
   double *dx2, *dy2;
   const double *cffr, *csr;
   // Red-black in the reference's SEQUENTIAL order at streaming speed (option "rb_seq", mgx_rbseq.hip): gk = T^-1 e1 of every column
-  // (the response of the column's tridiagonal system to a unit source in its bottom row; matrix only), ag5 / ag8 = gk(1) * cA(5|8,1,j,i)
-  // (2-D, one row of RS per plane) and u1 = what the plane-by-plane scan found: new minus old p(k=1) of every column of the colour
-  // in work (2-D, zero in the halo).  nullptr = not allocated (four colours, cmatrix='simple').
-  double *gk, *ag5, *ag8, *u1;
+  // (the response of the column's tridiagonal system to a unit source in its bottom row; matrix only), ag58 = the pairs gk(1) * cA(5,1,j,i),
+  // gk(1) * cA(8,1,j,i) (2-D, two values per column, rows of 2 * RS per plane) and u1 = what the plane-by-plane scan found: new minus old
+  // p(k=1) of every column of the colour in work (2-D, one row of RS per plane, zero in the halo).  nullptr = not allocated (four colours, cmatrix='simple').
+  double *gk, *ag58, *u1;
 };
 
 __host__ __device__ inline int jpos(const LevView &L, int j) { return (j & 1) ? L.HO + (j >> 1) : L.EO + (j >> 1); }

@@ -6,7 +6,7 @@
 // from plane i-1 only, and the column solve is linear in its right-hand side.  So, per colour:
 //   (a) the parallel colour pass (every kernel of mgx_relax*.hip, k=1 diagonals read from the snapshot p1 = "old" everywhere) gives y;
 //   (b) d0 = y(1) - p1 (k_rbseq_d0), then ONE wave walks the planes i = 1..nx (k_rbseq_scan):
-//         u(j,i) = d0(j,i) - ag5(j,i) u(j+1,i-1) - ag8(j,i) u(j-1,i-1),   ag5|8 = g(1,j,i) cA(5|8,1,j,i),  g = T^-1 e1
+//         u(j,i) = d0(j,i) - ag5(j,i) u(j+1,i-1) - ag8(j,i) u(j-1,i-1),   ag5|8 = g(1,j,i) cA(5|8,1,j,i),  g = T^-1 e1  (stored as pairs: ag58)
 //       u = new minus old bottom value of the column in the sequential order (zero in the halo: a halo cell is refreshed after the
 //       colour, mg_relax.f90:181, on one rank and on several alike);
 //   (c) p(:,j,i) = y(:,j,i) + g(:,j,i) s(j,i),  s = -cA(5,1,j,i) u(j+1,i-1) - cA(8,1,j,i) u(j-1,i-1)   (k_rbseq_apply, with the mirrors).
@@ -42,8 +42,8 @@ __global__ void k_rbseq_setup(LevView L) {
     L.gk[ko] = x;
   }
   const long long q = (long long)i * L.RS + c;
-  L.ag5[q] = x * L.cA[4][o];
-  L.ag8[q] = x * L.cA[7][o];
+  L.ag58[2 * q] = x * L.cA[4][o];       // the two multipliers of a column side by side: one 16-byte request in the walk
+  L.ag58[2 * q + 1] = x * L.cA[7][o];
 }
 
 // position of the first column of the colour inside a row of plane i: odd j -> HO + jh, even j -> EO + 1 + jh  (jh = 0..ny/2-1)
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
   const int jh0 = (wv * 64 + lane) * CPL;
   const long long RS = L.RS;
   double *__restrict__ u1 = L.u1;
-  const double *__restrict__ g5 = L.ag5, *__restrict__ g8 = L.ag8, *__restrict__ p = L.p, *__restrict__ p1 = L.p1;
+  const double *__restrict__ g58 = L.ag58, *__restrict__ p = L.p, *__restrict__ p1 = L.p1;
   __shared__ double edges[2][NW > 1 ? NW : 1][2];
-  VecD<CPL> rd[D], r5[D], r8[D], ro[D0IN ? D : 1];
+  VecD<CPL> rd[D], ro[D0IN ? D : 1];
+  VecD<2 * CPL> r58[D];   // (ag5, ag8) of the lane's columns
   double up[CPL];
   bool ok[CPL];
   int jc[CPL];
@@ -92,13 +93,12 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
     if (FULL) {                                                                                                  \
       if (D0IN) { __builtin_memcpy(&rd[slot], p + qp_ + jh0, sizeof(VecD<CPL>)); __builtin_memcpy(&ro[D0IN ? (slot) : 0], p1 + q_ + jh0, sizeof(VecD<CPL>)); } \
       else __builtin_memcpy(&rd[slot], u1 + q_ + jh0, sizeof(VecD<CPL>));                                        \
-      __builtin_memcpy(&r5[slot], g5 + q_ + jh0, sizeof(VecD<CPL>));                                             \
-      __builtin_memcpy(&r8[slot], g8 + q_ + jh0, sizeof(VecD<CPL>));                                             \
+      __builtin_memcpy(&r58[slot], g58 + 2 * (q_ + jh0), sizeof(VecD<2 * CPL>));                                 \
     } else {                                                                                                     \
       _Pragma("unroll") for (int q = 0; q < CPL; q++) {                                                          \
         if (D0IN) { rd[slot].v[q] = p[qp_ + jc[q]]; ro[D0IN ? (slot) : 0].v[q] = p1[q_ + jc[q]]; }               \
         else rd[slot].v[q] = u1[q_ + jc[q]];                                                                     \
-        r5[slot].v[q] = g5[q_ + jc[q]]; r8[slot].v[q] = g8[q_ + jc[q]];                                          \
+        r58[slot].v[2 * q] = g58[2 * (q_ + jc[q])]; r58[slot].v[2 * q + 1] = g58[2 * (q_ + jc[q]) + 1];          \
       }                                                                                                          \
     }                                                                                                            \
   }
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
         if (jodd) { ua = up[q]; ub = q > 0 ? up[q > 0 ? q - 1 : 0] : edge; }
         else { ub = up[q]; ua = q < CPL - 1 ? up[q < CPL - 1 ? q + 1 : 0] : edge; }
         const double d0 = D0IN ? rd[d].v[q] - ro[D0IN ? d : 0].v[q] : rd[d].v[q];
-        double t = __builtin_fma(-r5[d].v[q], ua, d0);
-        t = __builtin_fma(-r8[d].v[q], ub, t);
+        double t = __builtin_fma(-r58[d].v[2 * q], ua, d0);
+        t = __builtin_fma(-r58[d].v[2 * q + 1], ub, t);
         un.v[q] = (FULL || ok[q]) ? t : 0.0;
       }
       if (NW > 1) {
@@ -222,7 +222,7 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
     if (full) SCAN_CASE(CPLV, 2, true, NWV, D0V) else SCAN_CASE(CPLV, 2, false, NWV, D0V) }
   // small half-rows: one wave forms d0 itself (the level lives in L2; the walk is bound by its dependent chain, not by its requests)
   if (nyh <= 2 * WAVE && !d0_out) {
-    if (nyh <= WAVE) SCAN_CPL(1, 8, 1, true)
+    if (nyh <= WAVE) SCAN_CPL(1, 16, 1, true)   // y, snapshot, the multiplier pair, the store of u: 4 operations per plane, 16 planes deep
     SCAN_CPL(2, 8, 1, true)
   }
   hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
