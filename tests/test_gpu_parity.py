@@ -219,6 +219,43 @@ def test_relax_rb_sequential_order_at_speed(mg, dims, geom):
         assert np.abs(a - c).max() <= 1e-12 * np.abs(c).max(), (lev, np.abs(a - c).max() / np.abs(c).max())
 
 
+@pytest.mark.parametrize("case", ["bmask", "tall", "stretched", "user_matrix"])
+def test_rb_sequential_order_other_coefficient_paths(mg, case):
+    """The sequential-order red-black (default) where the colour pass runs other kernels / other coefficients than the seamount's matrix-free
+    ones: the masked system (bmask: stored coefficients, no in-kernel rebuild), nz = 128 (k_relax_tall with the snapshot), a stretched sigma
+    coordinate with a moving free surface, and a matrix handed in through set_field('cA') (g = T^-1 e1 is rebuilt with the pivots).  Three
+    sweeps per level from a rough random state against the oracle's sequential loop: 1e-12 of max|p|."""
+    from oracle.mgoracle import Oracle, seamount_geometry
+    from mgroms_amd.testcases import island_mask
+    nx, ny, nz = (16, 32, 128) if case == "tall" else (32, 64, 16)
+    kw = dict(relax_method="RB", bmask=(1 if case == "bmask" else 0))
+    mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(**kw))
+    dx, dy, zeta, h = seamount_geometry(nx, ny, 1, 1, 0)
+    hc, tb, ts = 4e3, 0.0, 0.0
+    if case == "stretched":
+        ii, jj = np.meshgrid(np.arange(nx + 2), np.arange(ny + 2), indexing="ij")
+        zeta = 0.4 * np.cos(0.25 * ii) * np.sin(0.15 * jj); hc, tb, ts = 250.0, 0.4, 6.0
+    rmask = island_mask(nx, ny) if case == "bmask" else None
+    mg.nhydro_matrices(dx, dy, zeta, h, rmask, hc, tb, ts)
+    o = Oracle(nx, ny, nz, 1, 1, relax_method="RB", bmask=(case == "bmask"))
+    for name, a in (("dx", dx), ("dy", dy), ("zeta", zeta), ("h", h)) + ((("rmask", rmask),) if case == "bmask" else ()):
+        o.field(name)[...] = a
+    o.matrices(hc, tb, ts)
+    if case == "user_matrix":   # the same coefficients, but through the stored-slot path of a user-supplied matrix
+        for lev in range(1, o.nlevs + 1):
+            mg.grid(lev).set("cA", o.field("cA", lev))
+    rng = np.random.default_rng(41)
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+        g.set("p", p); g.set("b", b); mg.fill_halo(lev, "p")
+        o.field("p", lev)[...] = p; o.field("b", lev)[...] = b; o.fill_halo(lev, "p")
+        mg.relax(lev, 3); o.relax(lev, 3)
+        a, c = g.get("p"), o.field("p", lev)
+        tol = 1e-12 if case != "stretched" else 1e-10   # the device's cosh / exp differ from libm's in the last bits of zr, zw (section 2)
+        assert np.abs(a - c).max() <= tol * np.abs(c).max(), (case, lev, np.abs(a - c).max() / np.abs(c).max())
+
+
 def test_solve_rb_sequential_order_golden(mg, golden):
     """The reference default on the reference's own recorded run (BASELINE.md 3.1, 64x64x16 on one rank, tol 1e-6): 15 iterations, every
     residual within 1e-13 + 1e-10*ref, sum(p^2) to 1e-10 -- at north_star's tolerance WITHOUT the per-plane launches of rb_exact."""
