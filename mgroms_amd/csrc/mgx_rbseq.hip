@@ -14,9 +14,11 @@
 // bit-exact order stays available as "rb_exact" (one launch per plane) and is what the tests compare against.
 //
 // Why one wave: the recurrence is sequential in i by nature (the cone of (j,i) widens by one column per plane in both directions), a
-// step is two fused multiply-adds per column, and what limits the walk is how fast ONE compute unit takes in 24 B per column
-// (~32 B/clk): the wave keeps D planes of operands in flight in registers (CPL columns per lane, contiguous, so the neighbours
-// j+-1 are the lane's own registers but for one value that crosses to the next lane by a DPP wave shift).
+// step is two fused multiply-adds per column; the wave keeps D planes of operands in flight in registers (CPL columns per lane,
+// contiguous, so the neighbours j+-1 are the lane's own registers but for one value that crosses to the next lane by a DPP wave
+// shift).  What a plane step costs is its instruction issue (~190 cycles: 4-8 memory instructions, the DPP + FMA chain) and, where the
+// operands live in HBM (level 1), the latency that at most 63 requests in flight per wave leave uncovered -- helper workgroups pull them
+// into the walking wave's L2 (k_rbseq_scan).
 #include <cstdlib>
 
 #include "mgx_device.h"
@@ -70,7 +72,30 @@ template <int N> struct VecD { double v[N]; };
 // compiler sinks all loads of a loop trip behind its last step and the trip waits for a full memory latency (measured: 99 us for the
 // 512 planes of level 1).  With NW > 1 the two values that cross between neighbouring waves go through LDS, one barrier per plane.
 template <int CPL, int D, int RBP, bool FULL, int NW, bool D0IN>
-__global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L) {
+__global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, int rb) {
+  if (blockIdx.x != 0) {
+    // Helper workgroups (nhelp of them, those with blockIdx % 8 == 0: dealt to the walking workgroup's XCD).  Every colour pass is a kernel
+    // boundary, after which the walk's operands come from the Infinity Cache / HBM (~1.4 us per request: 16 planes of look-ahead make
+    // 86 ns per plane, measured); the helpers ask for the same lines, many at a time, so that the walking wave finds them in the L2 it
+    // shares with them.  Speed only: nothing depends on where a workgroup lands or on whether a line is still there.
+    if ((blockIdx.x & 7) != 0) return;
+    const int h = (blockIdx.x >> 3) - 1, per = (L.nx + nhelp - 1) / nhelp, nyh_ = L.ny >> 1;
+    const int ia = 1 + h * per, ib = ia + per - 1 < L.nx ? ia + per - 1 : L.nx;
+    double acc = 0.0;
+    for (int i = ia; i <= ib; i++) {
+      const int off = rb_jodd(i, rb) ? L.HO : L.EO + 1;
+      const long long q = (long long)i * L.RS + off;
+      for (int t = threadIdx.x * 2; t < nyh_; t += 2 * 64 * NW) {   // 16-byte requests; a half-row is a multiple of 2 columns and starts 16-byte aligned
+        double2 a, b, c, d;
+        if (D0IN) { __builtin_memcpy(&a, L.p + (long long)i * L.plane + off + t, 16); __builtin_memcpy(&b, L.p1 + q + t, 16); }
+        else { __builtin_memcpy(&a, L.u1 + q + t, 16); b = a; }
+        __builtin_memcpy(&c, L.ag58 + 2 * (q + t), 16); __builtin_memcpy(&d, L.ag58 + 2 * (q + t) + 2, 16);
+        acc += a.x + b.y + c.x + d.y;
+      }
+    }
+    if (acc == 1.2345678e-301) L.u1[0] = acc;   // never: keeps the requests alive (row 0 of u1 is halo and stays zero)
+    return;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
   const int jh0 = (wv * 64 + lane) * CPL;
   const long long RS = L.RS;
@@ -208,11 +233,22 @@ void mgxk_rbseq_setup(hipStream_t st, const LevView *L) {
 int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
   const int nyh = L->ny / 2, nx = L->nx;
   if (L->gk == nullptr || nyh > 16 * WAVE || (nx & 1)) return 0;
-  static const bool one_wave = getenv("MGX_RBSEQ_ONE_WAVE") != nullptr, d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
+  static const bool two_waves = getenv("MGX_RBSEQ_TWO_WAVES") != nullptr, d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
   const int rbp = rb & 1;
+  // helper workgroups that pull the walk's operands into its L2 (k_rbseq_scan): one per ~32 KB of operands, at most 32 (one per compute unit of an XCD)
+  static const int help_env = getenv("MGX_RBSEQ_HELPERS") ? atoi(getenv("MGX_RBSEQ_HELPERS")) : -1;
+  // Measured (512x512x64, rocprofv3): level 1 (4.2 MB of operands, HBM-resident) one wave 88.4 us without helpers, 59.7 with 32; two waves
+  // (a barrier per plane) 73; levels 2-4 (1 MB and less) 20.9 / 11.0 / 7.6 us with or without them -- there the walk is bound by the ~190
+  // cycles a plane step costs to issue (4-5 memory instructions, the dependent DPP + FMA chain), and a few dozen extra workgroups only add
+  // launch time (level 4: 9.0 against 7.6).  So: helpers from 2 MB of operands on.
+  const long long opbytes = (long long)nx * nyh * 32;
+  int nhelp = opbytes >= (2LL << 20) ? (int)((opbytes + 131071) / 131072) : 0;
+  if (nhelp > 32) nhelp = 32;
+  if (nhelp > nx) nhelp = nx;
+  if (help_env >= 0) nhelp = help_env < nx ? help_env : nx;
 #define SCAN_CASE(CPLV, DV, FULLV, NWV, D0V)                                                                         \
-  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV, NWV, D0V>), dim3(1), dim3(WAVE * NWV), 0, st, *L); \
-    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV, NWV, D0V>), dim3(1), dim3(WAVE * NWV), 0, st, *L);     \
+  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV, NWV, D0V>), dim3(1 + 8 * nhelp), dim3(WAVE * NWV), 0, st, *L, nhelp, rb); \
+    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV, NWV, D0V>), dim3(1 + 8 * nhelp), dim3(WAVE * NWV), 0, st, *L, nhelp, rb);     \
     return 1; }
   // ring depth: D * (loads + stores per plane) < 63 (vmcnt), a divisor of nx
 #define SCAN_CPL(CPLV, DMAX, NWV, D0V)                                                                               \
@@ -229,9 +265,11 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
   if (nyh <= WAVE) SCAN_CPL(1, 16, 1, false)
   if (nyh <= 2 * WAVE) SCAN_CPL(2, 16, 1, false)
   // wide half-rows: the requests of ONE wave (at most 63 in flight) do not cover the latency of a level that lives in HBM: several waves
-  if (nyh == 4 * WAVE && !one_wave) SCAN_CPL(2, 16, 2, false)
-  if (nyh == 8 * WAVE && !one_wave) SCAN_CPL(2, 16, 4, false)
-  if (nyh == 16 * WAVE && !one_wave) SCAN_CPL(2, 16, 8, false)
+  // (256 columns per half-row: ONE wave with the helpers beats two waves with a barrier per plane, 59.7 against 73 us; wider half-rows
+  // -- 512 and 1024 columns, BASELINE config 5 -- would need 16 / 32 memory instructions per plane in one wave: several waves there, unmeasured)
+  if (nyh == 4 * WAVE && two_waves) SCAN_CPL(2, 16, 2, false)
+  if (nyh == 8 * WAVE) SCAN_CPL(2, 16, 4, false)
+  if (nyh == 16 * WAVE) SCAN_CPL(2, 16, 8, false)
   if (nyh <= 4 * WAVE) SCAN_CPL(4, 8, 1, false)
   if (nyh <= 8 * WAVE) SCAN_CPL(8, 4, 1, false)
   SCAN_CPL(16, 2, 1, false)
