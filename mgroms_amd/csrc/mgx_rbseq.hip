@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
   const int jh0 = (wv * 64 + lane) * CPL;
+  const unsigned int ujh0 = (unsigned int)jh0;
   const long long RS = L.RS;
   double *__restrict__ u1 = L.u1;
   const double *__restrict__ g58 = L.ag58, *__restrict__ p = L.p, *__restrict__ p1 = L.p1;
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
     const int off_ = (((((slot) + 1 + RBP) & 1) == 0) ? L.HO : L.EO + 1);                                        \
     const long long q_ = (long long)i_ * RS + off_, qp_ = (long long)i_ * L.plane + off_;                        \
     if (FULL) {                                                                                                  \
-      if (D0IN) { __builtin_memcpy(&rd[slot], p + qp_ + jh0, sizeof(VecD<CPL>)); __builtin_memcpy(&ro[D0IN ? (slot) : 0], p1 + q_ + jh0, sizeof(VecD<CPL>)); } \
-      else __builtin_memcpy(&rd[slot], u1 + q_ + jh0, sizeof(VecD<CPL>));                                        \
-      __builtin_memcpy(&r58[slot], g58 + 2 * (q_ + jh0), sizeof(VecD<2 * CPL>));                                 \
+      /* wave-uniform row pointers (scalar registers) + the lane's 32-bit column offset: one address per request, no 64-bit vector arithmetic */ \
+      const double *rp_ = p + qp_, *r1_ = p1 + q_, *ru_ = u1 + q_, *rg_ = g58 + 2 * q_;                           \
+      if (D0IN) { __builtin_memcpy(&rd[slot], rp_ + ujh0, sizeof(VecD<CPL>)); __builtin_memcpy(&ro[D0IN ? (slot) : 0], r1_ + ujh0, sizeof(VecD<CPL>)); } \
+      else __builtin_memcpy(&rd[slot], ru_ + ujh0, sizeof(VecD<CPL>));                                           \
+      __builtin_memcpy(&r58[slot], rg_ + 2u * ujh0, sizeof(VecD<2 * CPL>));                                      \
     } else {                                                                                                     \
       _Pragma("unroll") for (int q = 0; q < CPL; q++) {                                                          \
         if (D0IN) { rd[slot].v[q] = p[qp_ + jc[q]]; ro[D0IN ? (slot) : 0].v[q] = p1[q_ + jc[q]]; }               \
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
         if (lane == 63) edges[i & 1][wv][1] = un.v[CPL - 1];
       }
       const long long qo = (long long)i * RS + (jodd ? L.HO : L.EO + 1);
-      if (FULL) __builtin_memcpy(u1 + qo + jh0, &un, sizeof(VecD<CPL>));
+      if (FULL) { double *wu_ = u1 + qo; __builtin_memcpy(wu_ + ujh0, &un, sizeof(VecD<CPL>)); }
       else {
 #pragma unroll
         for (int q = 0; q < CPL; q++) if (ok[q]) u1[qo + jh0 + q] = un.v[q];
