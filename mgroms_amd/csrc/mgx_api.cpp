@@ -44,6 +44,7 @@ void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, S
 void mgxk_sumsq(hipStream_t, const LevView *, const double *, double *, double *);
 void mgxk_dot(hipStream_t, const LevView *, const double *, const double *, double *, double *);
 void mgxk_fine2coarse(hipStream_t, const LevView *, const LevView *, double *, Sides, double *dup, double *zero);
+void mgxk_restrict_chain(hipStream_t, const LevView *const *, int, Sides);
 int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero);
 int mgxk_residual_restrict_ex(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero, double *partial, double *dup);
 int mgxk_residual_restrict_grid(const LevView *, const LevView *);
@@ -188,6 +189,7 @@ struct State {
   // ~50 us), so the chain exchange -> boundary part -> exchange is no shorter than the serial one; the two cross-stream waits per colour come on top.
   int overlap = 0;       // option "overlap" / MGX_OVERLAP=1 (the same bits either way)
   long long n_overlap = 0;  // colour passes run that way
+  int use_chain = 1;     // option "restrict_chain" / MGX_NO_RESTRICT_CHAIN=1: Fcycle's first-leg restrictions below level 1 as one launch (A/B)
   int fuse_closing = 1;  // option "fuse_closing" / MGX_NO_FUSE_CLOSING=1: the closing compute_residual(1) of a solve_p iteration also restricts its r for the next Fcycle, one kernel, no r written (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
   long long n_launch = 0, n_halo = 0, n_exch = 0, n_allred = 0;
@@ -774,6 +776,23 @@ int fcycle(bool have_r2 = false) {
       C.b_halo_stale = true; S.n_launch += 2;
       continue;
     }
+    if (lev >= 2 && S.use_chain && !S.exact_halos) {
+      // the rest of the first leg (closed, un-gathered levels: a single rank, or everything below the gathers) as ONE launch, up to four levels at a time
+      int dep = 0;
+      const LevView *vs[5] = {&S.lev[lev - 1].v, nullptr, nullptr, nullptr, nullptr};
+      bool ok = true;
+      for (int q = lev - 1; q < S.nlevs && ok; q++) { const Level &Lq = S.lev[q]; ok = Lq.neighb[0] < 0 && Lq.neighb[1] < 0 && Lq.neighb[2] < 0 && Lq.neighb[3] < 0 && (q == lev - 1 || !Lq.gather); }
+      if (ok) {
+        while (dep < 4 && lev + dep < S.nlevs) { dep++; vs[dep] = &S.lev[lev - 1 + dep].v; }
+        const Level &F = S.lev[lev - 1];
+        if (dep >= 2 && F.nx % (1 << dep) == 0 && F.ny % (1 << dep) == 0 && F.nz % (1 << dep) == 0) {
+          const Sides all = {1, 1, 1, 1};
+          mgxk_restrict_chain(S.stream, vs, dep, all); S.n_launch++;
+          lev += dep - 1;
+          continue;
+        }
+      }
+    }
     CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
   CHK(relax(S.nlevs, S.par.ns_coarsest));
@@ -1326,7 +1345,7 @@ void mgx_clean(void) {
   if (S.ev_s) (void)hipEventDestroy(S.ev_s);
   if (S.ev_x) (void)hipEventDestroy(S.ev_x);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
   std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
@@ -1335,7 +1354,7 @@ void mgx_clean(void) {
   S = State();
   S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1462,6 +1481,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.no_mf = getenv("MGX_NO_MF") ? 1 : 0;
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
   if (getenv("MGX_NO_FUSE_CLOSING")) S.fuse_closing = 0;
+  if (getenv("MGX_NO_RESTRICT_CHAIN")) S.use_chain = 0;
   if (getenv("MGX_OVERLAP")) S.overlap = atoi(getenv("MGX_OVERLAP"));
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
@@ -1640,6 +1660,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "keep_r")) S.keep_r = value;
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "fuse_closing")) S.fuse_closing = value;
+  else if (streq(name, "restrict_chain")) S.use_chain = value;
   else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
@@ -1680,6 +1701,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "keep_r")) *value = S.keep_r;
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "fuse_closing")) *value = S.fuse_closing;
+  else if (streq(name, "restrict_chain")) *value = S.use_chain;
   else if (streq(name, "overlap")) *value = S.overlap;
   else if (streq(name, "overlapped_passes")) *value = (int)S.n_overlap;
   else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;

@@ -266,6 +266,55 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fcycle's first leg below level 1 (mg_solvers.f90:110-115): for lev = l0 .. l0+DEP-1: grid(lev+1)%b = restriction of grid(lev)%r,
+// grid(lev+1)%r = grid(lev+1)%b, grid(lev+1)%p = 0 -- a chain in which every level is the 8-cell sum of the one above and nothing else.
+// One workgroup takes a (2^DEP)^3 block of the finest level of the chain into LDS and carries it down DEP levels there (4096, 512, 64,
+// 8, 1 cells), storing every level's b, r and zeroed p with their physical images on the way: one launch instead of DEP (the small
+// levels are launch-bound: 6.3 + 5.5 + 4.6 + 4.3 us and three kernel boundaries for the 256x256x32 -> 16x16x2 chain of the bench).
+// Same 8-term sum in the same order as k_fine2coarse (left to right: (k,jA,iA) + (k,jA,iB) + (k,jB,iA) + (k,jB,iB), then the same of
+// k+1): bit-identical.  Closed levels only (the mirrors then reach every halo cell), none of them gathered.
+struct LevChain { LevView v[5]; };
+template <int DEP>
+__global__ __launch_bounds__(256) void k_restrict_chain(LevChain Ch, Sides ph) {
+  constexpr int E = 1 << DEP;
+  __shared__ double buf[E * E * E + (E / 2) * (E / 2) * (E / 2)];
+  double *cur = buf, *nxt = buf + E * E * E;
+  const LevView &F = Ch.v[0];
+  const int nbj = F.ny / E, nbk = F.nz / E;
+  int bb = blockIdx.x;
+  const int kb = bb % nbk; bb /= nbk;
+  const int jb = bb % nbj, ib = bb / nbj;
+  // the fine block, (i, k, j) with j split by parity so that a lane run is a contiguous half-row run: idx = (ii * E + kk) * E + jj
+  for (int t = threadIdx.x; t < E * E * E; t += 256) {
+    const int hj = t % (E / 2), par = (t / (E / 2)) & 1, kk = (t / E) % E, ii = t / (E * E);
+    const int jj = 2 * hj + par;               // 0-based inside the block: even jj = odd j (1-based)
+    const int i = ib * E + ii + 1, j = jb * E + jj + 1, k = kb * E + kk + 1;
+    cur[(ii * E + kk) * E + jj] = F.r[(long long)i * F.plane + (long long)(k - 1) * F.RS + jpos(F, j)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 1; d <= DEP; d++) {
+    const int e = E >> (d - 1), h = e >> 1;    // edge of the level above and of this one
+    const LevView &C = Ch.v[d];
+    for (int t = threadIdx.x; t < h * h * h; t += 256) {
+      const int jc = t % h, kc = (t / h) % h, ic = t / (h * h);
+      const int iA = 2 * ic, iB = iA + 1, k0 = 2 * kc, k1 = k0 + 1, jA = 2 * jc, jB = jA + 1;
+#define CH(ii_, kk_, jj_) cur[((ii_) * e + (kk_)) * e + (jj_)]
+      const double z = CH(iA, k0, jA) + CH(iB, k0, jA) + CH(iA, k0, jB) + CH(iB, k0, jB) + CH(iA, k1, jA) + CH(iB, k1, jA) + CH(iA, k1, jB) + CH(iB, k1, jB);
+#undef CH
+      nxt[(ic * h + kc) * h + jc] = z;
+      const int i2 = ib * h + ic + 1, j2 = jb * h + jc + 1, k2 = kb * h + kc + 1, cj = jpos(C, j2);
+      const long long rc = (long long)(k2 - 1) * C.RS, oc = (long long)i2 * C.plane + rc + cj;
+      C.b[oc] = z; mirror_store(C, C.b, rc, j2, i2, cj, z, ph);
+      C.r[oc] = z; mirror_store(C, C.r, rc, j2, i2, cj, z, ph);
+      C.p[oc] = 0.0; mirror_store(C, C.p, rc, j2, i2, cj, 0.0, ph);
+    }
+    __syncthreads();
+    double *sw = cur; cur = nxt; nxt = sw;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // restriction: coarse b = sum of the 8 fine r.  mg_intergrids.f90:139-162.  One lane = one coarse column.
 // `dst` is the coarse b, or the pre-gather block (nxc x nyc) when the coarse level is gathered.
 // ------------------------------------------------------------------------------------------------
@@ -821,6 +870,21 @@ void mgxk_dot(hipStream_t st, const LevView *L, const double *a, const double *b
   dim3 blk(WAVE, 4), grd = col_grid(L->ny / 2, L->nx, 2);
   hipLaunchKernelGGL(k_dot, grd, blk, 0, st, *L, a, b, partial);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, partial, (int)(grd.x * grd.y * grd.z), out);
+}
+// levels[0 .. dep]: the views of lev, lev+1, ... (dep restrictions, 1 <= dep <= 4); every level closed, not gathered, level 0's nx, ny, nz multiples of 2^dep
+void mgxk_restrict_chain(hipStream_t st, const LevView *const *levels, int dep, Sides ph) {
+  LevChain Ch;
+  for (int q = 0; q <= dep && q < 5; q++) Ch.v[q] = *levels[q];
+  for (int q = dep + 1; q < 5; q++) Ch.v[q] = *levels[dep];
+  const LevView &F = Ch.v[0];
+  const int E = 1 << dep;
+  const dim3 grd((unsigned)((F.nx / E) * (F.ny / E) * (F.nz / E)));
+  switch (dep) {
+    case 1: hipLaunchKernelGGL(k_restrict_chain<1>, grd, dim3(256), 0, st, Ch, ph); break;
+    case 2: hipLaunchKernelGGL(k_restrict_chain<2>, grd, dim3(256), 0, st, Ch, ph); break;
+    case 3: hipLaunchKernelGGL(k_restrict_chain<3>, grd, dim3(256), 0, st, Ch, ph); break;
+    default: hipLaunchKernelGGL(k_restrict_chain<4>, grd, dim3(256), 0, st, Ch, ph); break;
+  }
 }
 void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double *dst, Sides ph, double *dup, double *zero) {
   dim3 grd = col_grid(C->ny, C->nx);

@@ -881,6 +881,41 @@ def test_vcycle2_and_fcycle_ops(mg):
         assert np.array_equal(mg.grid(lev).p, o.field("p", lev)), lev
 
 
+@pytest.mark.parametrize("dims", [(128, 128, 32), (64, 128, 16), (256, 256, 64), (32, 32, 8)])
+def test_fcycle_first_leg_as_one_launch(mg, dims):
+    """Fcycle's first leg below level 1 (mg_solvers.f90:110-115: restrict r, r_c = b_c, p_c = 0, level after level) runs as ONE launch that carries a
+    block of the finest level of the chain down through LDS (k_restrict_chain; up to four levels at a time).  A/B against one launch per level
+    (option "restrict_chain" = 0): b, r and p of every level right after an F-cycle, and the solve's history -- the same bits; against the
+    oracle too; and it did take launches out."""
+    nx, ny, nz = dims
+    res = []
+    for chain in (1, 0):
+        mg.nhydro.set_option("restrict_chain", chain)
+        try:
+            o = _setup(mg, nx, ny, nz)
+            u, v, w = _uvw(nx, ny, nz, seed=3)
+            mg.nhydro.compute_rhs(u, v, w)
+            mg.compute_residual(1)
+            c0 = mg.nhydro.counters()["launches"]
+            mg.Fcycle()
+            c1 = mg.nhydro.counters()["launches"]
+            got = [mg.grid(l).get(f) for l in range(1, mg.nlevs() + 1) for f in ("p", "b")]
+            n, hist = mg.solve_p(1e-30, 2)
+            got += [mg.grid(1).p, hist]
+            res.append((got, c1 - c0))
+            if chain:
+                o.field("u")[...] = u; o.field("v")[...] = v; o.field("w")[...] = w
+                o.compute_rhs(); o.residual(1); o.fcycle()
+                for l in range(1, o.nlevs + 1):
+                    assert np.array_equal(got[2 * (l - 1)], o.field("p", l)) and np.array_equal(got[2 * (l - 1) + 1], o.field("b", l)), l
+        finally:
+            mg.nhydro.set_option("restrict_chain", 1)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    if mg.nlevs() >= 4:
+        assert res[0][1] < res[1][1]
+
+
 def test_cycle_keeps_the_dead_r_on_request(mg):
     # coarse2fine leaves the interpolated correction in the fine r (mg_intergrids.f90:218-226); nothing reads it before the next
     # compute_residual, so the cycles skip that store unless "keep_r" (or "exact_halos") asks for the reference's state
