@@ -30,7 +30,7 @@ if f2c:
     out["calibration"] = {"kernel": "k_fine2coarse", "FETCH_SIZE_KiB": f2c, "bytes_actually_read": cells * 8,
                           "ratio": cells * 8 / (f2c * 1024)}
 for k in sorted(set(fetch) | set(write)):
-    if not (k.startswith("k_relax") or k.startswith("k_residual") or k.startswith("k_coarse2fine") or k.startswith("k_fine2coarse")):
+    if not k.startswith(("k_relax", "k_residual", "k_coarse2fine", "k_fine2coarse", "k_rbseq", "k_restrict_chain")):
         continue
     fb, wb = 2.0 * fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
     out["kernels"][k] = {"FETCH_SIZE_KiB_raw": fetch.get(k), "WRITE_SIZE_KiB_raw": write.get(k),
