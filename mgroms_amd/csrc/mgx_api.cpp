@@ -37,6 +37,8 @@ int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 void mgxk_rbseq_setup(hipStream_t, const LevView *);
 int mgxk_rbseq_scan(hipStream_t, const LevView *, int);
+int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, unsigned int *, unsigned int, int *, int, long long);
+int mgxk_set_rbseq_timeout(double);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
@@ -124,6 +126,7 @@ struct Level {
   size_t p2p_goff[2];           // gathered levels: ngroup blocks of the peer-to-peer gather, by parity
   unsigned long long p2p_gseq = 0;
   unsigned int *ksp_done = nullptr; unsigned int ksp_seq = 0;  // per-plane progress counters of the persistent mid-level relax (k_relax_ksp) and their common value
+  unsigned int *rbs_flag = nullptr; unsigned int rbs_seq = 0;  // progress word of the sequential-order red-black walk and the number of its launches (mgx_rbseq.hip: k_rbseq_scan, FUSE)
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
   double *f2d_store[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *tab_store[2] = {nullptr, nullptr};  // m4,d4,m7,d7,h2,hi2,ze2 and cffw,csw (LevView)
@@ -189,6 +192,9 @@ struct State {
   // ~50 us), so the chain exchange -> boundary part -> exchange is no shorter than the serial one; the two cross-stream waits per colour come on top.
   int overlap = 0;       // option "overlap" / MGX_OVERLAP=1 (the same bits either way)
   long long n_overlap = 0;  // colour passes run that way
+  int rbseq_fuse_min = 4 << 20;  // option "rbseq_fuse_min": cells of a colour (nx * ny/2 * nz) from which on the fused launch is used (below, the hand-off costs more than the correction's own launch: 256x256x32 0.111 ms per sweep fused, 0.099 separate)
+  int rbseq_test_stall = 0;  // test hook: the walk of the fused launch never reports its progress (the bounded waits must end the launch)
+  int rbseq_fuse = 1;    // option "rbseq_fuse" / MGX_NO_RBSEQ_FUSE=1: the correction of the sequential-order red-black inside the walk's launch (k_rbseq_scan, FUSE) instead of a launch behind it (A/B)
   int use_chain = 1;     // option "restrict_chain" / MGX_NO_RESTRICT_CHAIN=1: Fcycle's first-leg restrictions below level 1 as one launch (A/B)
   int fuse_closing = 1;  // option "fuse_closing" / MGX_NO_FUSE_CLOSING=1: the closing compute_residual(1) of a solve_p iteration also restricts its r for the next Fcycle, one kernel, no r written (A/B)
   int c2f_skip = 1;   // the cycles' prolongation leaves the columns alone that the first colour of the following four-colour relax overwrites unread (option "c2f_skip", MGX_C2F_NOSKIP=1)
@@ -573,8 +579,12 @@ int relax(int lev, int nsweeps) {
         if (seq) {
           // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
-          if (!mgxk_rbseq_scan(S.stream, &L.v, rb)) return fail("rb_seq: level %d (ny = %d) has no scan instance; set option rb_exact or rb_seq = 0", lev, L.ny);
-          mgxk_rbseq_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0); S.n_launch += 3;
+          // (where an instance exists the correction runs inside the walk's launch, chasing it: option "rbseq_fuse")
+          const int ran = S.rbseq_fuse ? mgxk_rbseq_scan_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0, L.rbs_flag, ++L.rbs_seq, S.kerr, S.rbseq_test_stall, (long long)S.rbseq_fuse_min) : mgxk_rbseq_scan(S.stream, &L.v, rb);
+          if (ran == 2) S.rbseq_test_stall = 0;
+          if (!ran) return fail("rb_seq: level %d (ny = %d) has no scan instance; set option rb_exact or rb_seq = 0", lev, L.ny);
+          if (ran == 1) { mgxk_rbseq_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0); S.n_launch++; }
+          S.n_launch += 2;
           fused = 1;  // the correction stores the physical images of every column it updates
         }
         CHK(fill_halo_js(L, L.v.p, fused));
@@ -1066,6 +1076,14 @@ int sync_stream() {
     mgx_pending_error = hipSuccess;
     if (le != hipSuccess) return fail("a HIP call of this thread failed since the last synchronisation (a rejected kernel launch, or an earlier call of the host program): %s", hipGetErrorString(le));
   }
+  if (S.kerr && *S.kerr == 2) {
+    // the fused sequential-order red-black launch: a forwarding wave did not see the walk's progress within 2 s, or found itself on another
+    // XCD than the walk (mgx_rbseq.hip).  The correction of that colour used stale values: the fused launch is OFF from now on.
+    *S.kerr = 0;
+    S.rbseq_fuse = 0; S.rbseq_test_stall = 0;
+    return fail("the fused red-black walk + correction launch lost its hand-off (forwarding waves timed out or ran on another XCD than the walk); "
+                "the fields of that level are wrong -- it is now OFF (option rbseq_fuse = 0: the correction in a launch of its own)");
+  }
   if (S.kerr && *S.kerr) {
     // a workgroup of the persistent relax kernel waited 2 s for its neighbour plane: some of its workgroups were kept off the chip
     // (the GPU is shared with kernels that do not finish).  The sweep is incomplete: counters back to zero, the separate launches from now on.
@@ -1345,7 +1363,7 @@ void mgx_clean(void) {
   if (S.ev_s) (void)hipEventDestroy(S.ev_s);
   if (S.ev_x) (void)hipEventDestroy(S.ev_x);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, rf = S.rbseq_fuse, rfm = S.rbseq_fuse_min, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
   std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
@@ -1354,7 +1372,7 @@ void mgx_clean(void) {
   S = State();
   S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.rbseq_fuse = rf; S.rbseq_fuse_min = rfm; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1416,6 +1434,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     if (S.method == M_RB && S.real) {  // sequential-order red-black (mgx_rbseq.hip): +8 B per cell
       CHK(dmalloc(&L.v.gk, L.n3js));
       CHK(dmalloc(&L.v.ag58, (size_t)2 * (L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
+      { double *q = nullptr; CHK(dmalloc(&q, (size_t)(L.nx / 8 + 2) * 8 + 16)); L.rbs_flag = (unsigned int *)q; L.rbs_seq = 0; }  // one word per chunk of 8 planes, 64 B apart (zeroed by dmalloc): what the walk has handed to the correction workers
     }
     const size_t n2 = (size_t)(L.ny + 2) * (L.nx + 2);
     L.g.nx = L.nx; L.g.ny = L.ny; L.g.nz = L.nz;
@@ -1482,6 +1501,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (getenv("MGX_C2F_NOSKIP")) S.c2f_skip = 0;
   if (getenv("MGX_NO_FUSE_CLOSING")) S.fuse_closing = 0;
   if (getenv("MGX_NO_RESTRICT_CHAIN")) S.use_chain = 0;
+  if (getenv("MGX_NO_RBSEQ_FUSE")) S.rbseq_fuse = 0;
   if (getenv("MGX_OVERLAP")) S.overlap = atoi(getenv("MGX_OVERLAP"));
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
@@ -1661,11 +1681,15 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "c2f_skip")) S.c2f_skip = value;
   else if (streq(name, "fuse_closing")) S.fuse_closing = value;
   else if (streq(name, "restrict_chain")) S.use_chain = value;
+  else if (streq(name, "rbseq_fuse")) S.rbseq_fuse = value;
   else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
   else if (streq(name, "fuse_tail")) S.use_fuse = value;
   else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
+  else if (streq(name, "rbseq_test_stall")) S.rbseq_test_stall = value;
+  else if (streq(name, "rbseq_fuse_min")) S.rbseq_fuse_min = value;
+  else if (streq(name, "rbseq_timeout_ms")) { if (mgxk_set_rbseq_timeout((double)value)) return fail("rbseq_timeout_ms: could not set the device constant"); }
   else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
   else if (streq(name, "p2p_timeout_ms")) { if (mgxk_set_p2p_timeout((double)value)) return fail("p2p_timeout_ms: could not set the device constant"); }
@@ -1702,6 +1726,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "c2f_skip")) *value = S.c2f_skip;
   else if (streq(name, "fuse_closing")) *value = S.fuse_closing;
   else if (streq(name, "restrict_chain")) *value = S.use_chain;
+  else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
+  else if (streq(name, "rbseq_fuse_min")) *value = S.rbseq_fuse_min;
   else if (streq(name, "overlap")) *value = S.overlap;
   else if (streq(name, "overlapped_passes")) *value = (int)S.n_overlap;
   else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;
@@ -1954,3 +1980,13 @@ int mgx_p2p_connect(const void *all_handles, int nranks) {
 }
 
 }  // extern "C"
+
+#ifdef MGX_RBSEQ_TRACE
+extern "C" int mgx_debug_rbs(int lev, unsigned long long *out8) {
+  auto &L = S.lev[lev - 1];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(out8, L.rbs_flag + (L.nx / 8 + 2) * 16, 64, hipMemcpyDeviceToHost);
+  (void)hipMemset(L.rbs_flag + (L.nx / 8 + 2) * 16, 0, 64);
+  return 0;
+}
+#endif

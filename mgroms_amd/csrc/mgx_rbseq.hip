@@ -71,21 +71,126 @@ template <int N> struct VecD { double v[N]; };
 // (vmcnt), i.e. D * (loads + stores per plane) must stay below that, and every step ends in a scheduling barrier -- without it the
 // compiler sinks all loads of a loop trip behind its last step and the trip waits for a full memory latency (measured: 99 us for the
 // 512 planes of level 1).  With NW > 1 the two values that cross between neighbouring waves go through LDS, one barrier per plane.
-template <int CPL, int D, int RBP, bool FULL, int NW, bool D0IN>
-__global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, int rb) {
+//
+// FUSE (1: with the correction, 2: ... which also keeps the snapshot current): the correction (c) runs INSIDE this launch, chasing the walk.  The
+// walk is one wave on one compute unit for ~55 us on level 1 while the other 255 idle, and the correction of plane i needs nothing but
+// u of plane i-1: the workgroups whose index is not a multiple of 8 (dealt to the seven XCDs the walk does not run on: its operands stay
+// in ITS L2) hold four correction workers each, one per wave, in plane order (rbseq_worker).
+// Hand-off (MI355X_MICROARCH.md "Valid forms"; the XCDs' L2s are not coherent with each other).  The walking wave cannot store u
+// write-through itself: vmcnt retires loads and stores in issue order, so every operand request would wait for the ~2.5 us a write-through
+// acknowledge takes (measured: 117 -> 320 ns per plane).  It stores u as before (acknowledged by its L2) and reports in a word of its own
+// how far it is -- plane i - D once step i has computed: the operands of step i were requested after u(i-D) was stored, and they are
+// back.  Four FORWARDING waves -- one workgroup of the walk's XCD (index a multiple of 8: the same L2), not of its compute unit (there
+// their write-through traffic slowed the walk from 54 to 82 us) -- take the chunks of RBF_CH planes in turn: wait for the chunk (sc1
+// poll of the progress word: served by the L2 the walk writes to), read its u past the L1 (sc1 loads), store it back write-through
+// (sc1), wait for every acknowledge (vmcnt(0)), then set the chunk's word (sc1 store of this launch's number).  The workers poll that
+// word with sc1 loads and read u with sc1 loads only.  All words count on from launch to launch (compared as signed differences), so
+// nothing has to reset them.
+// Every wait is bounded.  The walk waits for nobody and its workgroup is dispatched first; the forwarding waves wait for the walk,
+// the workers for the forwarding waves.  What the forwarding waves rely on beyond that -- being on the walk's XCD -- is checked
+// before the first use (rbseq_placement_ok: workgroups 0, 8, 16 ... of a launch share an XCD) and again in the kernel (the walk leaves
+// its XCC_ID next to the progress word); a wait that lasts 2 s or a wrong XCD sets *err (reported by the next synchronising call,
+// which turns the fused launch off), releases every word and lets the launch drain.
+struct RbFuse { Sides ph; int KR, nt, nchunk, nkz, nworkers, test_stall; long long min_cells; unsigned int *flag; unsigned int seq; int *err; };
+#ifdef MGX_RBSEQ_TRACE   // time stamps of the last fused launch (scripts/probe_rbseq_sweep.py), 100 MHz ticks, behind the words
+#define RBT(slot, op) { unsigned long long *T_ = (unsigned long long *)(F.flag + (L.nx / RBF_CH + 2) * RBF_FS); const unsigned long long t_ = wall_clock64(); op(T_ + (slot), t_); }
+__device__ __forceinline__ void rbt_set(unsigned long long *a, unsigned long long t) { *a = t; }
+__device__ __forceinline__ void rbt_max(unsigned long long *a, unsigned long long t) { atomicMax(a, t); }
+#else
+#define RBT(slot, op) {}
+#endif
+// forwarding waves, workers per workgroup, planes per chunk, words between two chunk words (64 B), batches of eight rows a worker holds at most
+constexpr int RBF_NF = 4, RBF_WPB = 4, RBF_CH = 8, RBF_FS = 16, RBF_NB = 4;
+__device__ long long g_rbs_timeout_ticks = 200000000LL;  // 2 s of the 100 MHz clock (mgxk_set_rbseq_timeout shortens it for the test)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned int rbs_xcc_id() { return (unsigned int)__builtin_amdgcn_s_getreg(20 | (3 << 11)); }  // hwreg(HW_REG_XCC_ID, 0, 4)
+// wait until *word has reached `need` (signed difference); false = timed out
+template <int NAPS>
+__device__ __forceinline__ bool rbs_wait(const unsigned int *word, unsigned int need) {
+  if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0) return true;
+  const long long t0 = wall_clock64(), tmax = g_rbs_timeout_ticks;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(NAPS);
+    if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0) return true;
+    if (wall_clock64() - t0 > tmax) return false;
+  }
+}
+template <bool SNAPW>
+__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, const unsigned int *word);
+
+template <int CPL, int D, int RBP, bool FULL, int NW, bool D0IN, int FUSE>
+__global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(LevView L, int nhelp, int rb, RbFuse F) {
+  static_assert(!FUSE || (NW == 1 && FULL && D % RBF_CH == 0), "fused instances: one walking wave, full half-rows, whole chunks per ring");
+  if (FUSE && (blockIdx.x & 7) != 0) {
+    // four workers per workgroup, consecutive in plane order: ONE wave polls, for the last of them (1792 resident waves polling every
+    // ~0.1 us would saturate the memory channel the words live on)
+    const int wid0 = ((int)(blockIdx.x >> 3) * 7 + (int)(blockIdx.x & 7) - 1) * RBF_WPB, wid = wid0 + (int)(threadIdx.x >> 6);
+    if (wid0 >= F.nworkers) return;
+    const int per = F.nkz * F.nchunk;
+    const int widl = wid0 + RBF_WPB - 1 < F.nworkers ? wid0 + RBF_WPB - 1 : F.nworkers - 1, il = 1 + widl / per;
+    const bool live = wid < F.nworkers;
+    const int w = live ? wid : F.nworkers - 1;
+    const int kz = w % F.nkz, ch = (w / F.nkz) % F.nchunk, i = 1 + w / per;
+    // plane 0 is halo: u = 0 there, always
+    rbseq_worker<FUSE == 2>(L, rb, F, ch * WAVE + (int)(threadIdx.x & 63), i, kz, live, il > 1 ? F.flag + ((il - 2) / RBF_CH) * RBF_FS : nullptr);
+    if (live && (threadIdx.x & 63) == 0) RBT(7, rbt_max)
+    return;
+  }
+  if (FUSE && blockIdx.x == 0) {
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x == 0) F.flag[(L.nx / RBF_CH) * RBF_FS + 1] = (F.seq << 4) | rbs_xcc_id();
+    if (threadIdx.x == 0) RBT(0, rbt_set)
+  }
+  if (FUSE && blockIdx.x == 8u * (nhelp + 1)) {
+    // the forwarding waves
+    const int f = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(L.u1, 0, 0x7fffffff, 0x00020000);
+    constexpr int LPP = CPL >= 2 ? CPL / 2 : 1;   // 16-byte requests per lane and plane (half-row = CPL * 64 columns)
+    const unsigned int *pw = F.flag + (L.nx / RBF_CH) * RBF_FS;
+    bool bail = false;
+    for (int c = f; c * RBF_CH < L.nx; c += RBF_NF) {
+      const int ia = c * RBF_CH + 1;
+      if (!bail) {
+        bail = !rbs_wait<8>(pw, (F.seq << 13) + (unsigned int)(ia + RBF_CH - 1));
+        if (!bail && c == f) bail = __hip_atomic_load(pw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ((F.seq << 4) | rbs_xcc_id());
+        if (bail && lane == 0) *F.err = 2;
+      }
+      if (!bail) {
+        u32x4 v[RBF_CH * LPP];
+        unsigned int off[RBF_CH * LPP];
+#pragma unroll
+        for (int d = 0; d < RBF_CH; d++) {
+          const int i = ia + d;
+#pragma unroll
+          for (int t = 0; t < LPP; t++) {
+            off[d * LPP + t] = (unsigned int)(((long long)i * L.RS + (rb_jodd(i, rb) ? L.HO : L.EO + 1) + (t * 64 + lane) * 2) * 8);
+            if (CPL >= 2 || lane < 32) v[d * LPP + t] = __builtin_amdgcn_raw_buffer_load_b128(urs, (int)off[d * LPP + t], 0, 16);  // aux 16 = sc1
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < RBF_CH * LPP; q++) if (CPL >= 2 || lane < 32) __builtin_amdgcn_raw_buffer_store_b128(v[q], urs, (int)off[q], 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (lane == 0) __hip_atomic_store(F.flag + c * RBF_FS, F.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) RBT(2, rbt_max)
+    }
+    return;
+  }
   if (blockIdx.x != 0) {
     // Helper workgroups (nhelp of them, those with blockIdx % 8 == 0: dealt to the walking workgroup's XCD).  Every colour pass is a kernel
     // boundary, after which the walk's operands come from the Infinity Cache / HBM (~1.4 us per request: 16 planes of look-ahead make
     // 86 ns per plane, measured); the helpers ask for the same lines, many at a time, so that the walking wave finds them in the L2 it
     // shares with them.  Speed only: nothing depends on where a workgroup lands or on whether a line is still there.
     if ((blockIdx.x & 7) != 0) return;
-    const int h = (blockIdx.x >> 3) - 1, per = (L.nx + nhelp - 1) / nhelp, nyh_ = L.ny >> 1;
-    const int ia = 1 + h * per, ib = ia + per - 1 < L.nx ? ia + per - 1 : L.nx;
+    const int h = (blockIdx.x >> 3) - 1;
+    if (h >= nhelp) return;   // (a fused launch has more workgroups on this XCD than helpers)
+    // planes h+1, h+1+nhelp, ...: the helpers' front advances in the walk's order, nhelp planes at a time
+    const int nyh_ = L.ny >> 1;
     double acc = 0.0;
-    for (int i = ia; i <= ib; i++) {
+    for (int i = 1 + h; i <= L.nx; i += nhelp) {
       const int off = rb_jodd(i, rb) ? L.HO : L.EO + 1;
       const long long q = (long long)i * L.RS + off;
-      for (int t = threadIdx.x * 2; t < nyh_; t += 2 * 64 * NW) {   // 16-byte requests; a half-row is a multiple of 2 columns and starts 16-byte aligned
+      for (int t = threadIdx.x * 2; t < nyh_; t += 2 * (int)blockDim.x) {   // 16-byte requests; a half-row is a multiple of 2 columns and starts 16-byte aligned
         double2 a, b, c, d;
         if (D0IN) { __builtin_memcpy(&a, L.p + (long long)i * L.plane + off + t, 16); __builtin_memcpy(&b, L.p1 + q + t, 16); }
         else { __builtin_memcpy(&a, L.u1 + q + t, 16); b = a; }
@@ -96,13 +201,14 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
     if (acc == 1.2345678e-301) L.u1[0] = acc;   // never: keeps the requests alive (row 0 of u1 is halo and stays zero)
     return;
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
+  const int lane = threadIdx.x & 63, wv = FUSE ? 0 : threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
   const int jh0 = (wv * 64 + lane) * CPL;
   const unsigned int ujh0 = (unsigned int)jh0;
   const long long RS = L.RS;
   double *__restrict__ u1 = L.u1;
   const double *__restrict__ g58 = L.ag58, *__restrict__ p = L.p, *__restrict__ p1 = L.p1;
   __shared__ double edges[2][NW > 1 ? NW : 1][2];
+  constexpr int PUB = D < 4 ? D : 4;  // planes between two publications of the progress word
   VecD<CPL> rd[D], ro[D0IN ? D : 1];
   VecD<2 * CPL> r58[D];   // (ag5, ag8) of the lane's columns
   double up[CPL];
@@ -137,6 +243,9 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
 #pragma unroll
   for (int d = 0; d < D; d++) { LOADP(1 + d, d) asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }  // slot by slot, as the loop issues them: the waits at the loop head are the minimum of both orders
   for (int i0 = 1; i0 <= nx; i0 += D) {
+#ifdef MGX_RBSEQ_TRACE
+    if (FUSE && lane == 0) { if (i0 == 1 + nx / 4) RBT(3, rbt_set) if (i0 == 1 + nx / 2) RBT(4, rbt_set) if (i0 == 1) RBT(5, rbt_set) if (i0 == 1 + 32) RBT(6, rbt_set) }
+#endif
 #pragma unroll
     for (int d = 0; d < D; d++) {
       const int i = i0 + d;
@@ -175,9 +284,19 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
       LOADP(i + D, d)
       if (NW > 1) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
+      if (FUSE && ((d + 1) % PUB) == 0 && i > D) {
+        // this step has consumed operands requested after u(i - D) was stored: planes <= i - D are in the L2
+        if (lane == 0 && !F.test_stall) F.flag[(nx / RBF_CH) * RBF_FS] = (F.seq << 13) + (unsigned int)(i - D);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 #undef LOADP
+  if (FUSE) {
+    if (lane == 0) RBT(1, rbt_set)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && !F.test_stall) F.flag[(nx / RBF_CH) * RBF_FS] = (F.seq << 13) + (unsigned int)nx;
+  }
 }
 
 // Measured and dropped (round 4): the walk with LOADER waves -- eight waves keep four chunks of requests in flight each, form d0 on the way
@@ -190,8 +309,7 @@ __global__ __launch_bounds__(64 * NW) void k_rbseq_scan(LevView L, int nhelp, in
 // the new bottom value into the snapshot p1 (and its mirrors), so that a closed level needs no snapshot launch before the next pass.
 // One wave = 64 columns of a plane x the rows [kz*KR, (kz+1)*KR).
 template <int KU, bool SNAPW>
-__global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph, int KR, int nt) {
-  const int jh = blockIdx.x * WAVE + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+__device__ __forceinline__ void rbseq_apply_cols(const LevView &L, int rb, const Sides &ph, int KR, int nt, int jh, int i, int kz) {
   if (jh >= (L.ny >> 1) || i > L.nx) return;
   const int jodd = rb_jodd(i, rb);
   int c, jm, jp;
@@ -203,7 +321,7 @@ __global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph
   const double s = 0.0 - L.cA[4][o + c] * L.u1[qm + jp] - L.cA[7][o + c] * L.u1[qm + jm];
   double *__restrict__ p = L.p;
   const double *__restrict__ g = L.gk;
-  const int k0 = blockIdx.z * KR;
+  const int k0 = kz * KR;
   for (int kb = k0; kb < k0 + KR; kb += KU) {
     double pv[KU], gv[KU];
 #pragma unroll
@@ -226,14 +344,113 @@ __global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph
   }
 }
 
+template <int KU, bool SNAPW>
+__global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph, int KR, int nt) {
+  rbseq_apply_cols<KU, SNAPW>(L, rb, ph, KR, nt, blockIdx.x * WAVE + threadIdx.x, 1 + blockIdx.y * blockDim.y + threadIdx.y, blockIdx.z);
+}
+
+// (c) as a worker of the fused launch (k_rbseq_scan, FUSE): the same arithmetic as rbseq_apply_cols.  What does not depend on the walk -- y
+// and g of the worker's rows (at most 32: four batches of eight), the two couplings -- is requested BEFORE the wait for the walk, so a
+// worker that has waited finishes one memory latency after its word is set (the tail of the launch behind the walk's last plane).
+// `word` (wave 0 of the workgroup polls it, the others wait at the barrier): the chunk of plane i-1 of the workgroup's LAST worker;
+// every load of u is an sc1 load.
+template <bool SNAPW>
+__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, const unsigned int *word) {
+  const int jodd = rb_jodd(i, rb);
+  int c, jm, jp;
+  if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
+  else      { c = L.EO + jh + 1; jm = L.HO + jh; jp = jm + 1; }
+  const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
+  const long long o = (long long)i * L.plane;
+  const long long qm = (long long)(i - 1) * L.RS;
+  double *__restrict__ p = L.p;
+  const double *__restrict__ g = L.gk;
+  const int k0 = kz * F.KR, nb = F.KR / 8, nt = F.nt;
+  double pv[RBF_NB][8], gv[RBF_NB][8], c5 = 0.0, c8 = 0.0;
+  if (live) {
+    c5 = L.cA[4][o + c]; c8 = L.cA[7][o + c];
+#pragma unroll
+    for (int b = 0; b < RBF_NB; b++)
+      if (b < nb) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) { const long long ko = o + (long long)(k0 + 8 * b + t) * L.RS + c; pv[b][t] = p[ko]; gv[b][t] = ld_rt(g + ko, nt); }
+      }
+  }
+  if (threadIdx.x < 64 && word != nullptr && !rbs_wait<16>(word, F.seq) && threadIdx.x == 0) *F.err = 2;
+  __syncthreads();
+  if (!live) return;
+  const double ujp = __hip_atomic_load(L.u1 + qm + jp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double ujm = __hip_atomic_load(L.u1 + qm + jm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double s = 0.0 - c5 * ujp - c8 * ujm;
+#pragma unroll
+  for (int b = 0; b < RBF_NB; b++)
+    if (b < nb) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int k = k0 + 8 * b + t;
+        const long long ro = (long long)k * L.RS;
+        const double v = pv[b][t] + gv[b][t] * s;
+        p[o + ro + c] = v;
+        mirror_store(L, p, ro, j, i, c, v, F.ph);
+        if (SNAPW && k == 0) {
+          LevView L2 = L; L2.plane = L.RS;  // the snapshot: one row per plane
+          L.p1[(long long)i * L.RS + c] = v;
+          mirror_store(L2, L.p1, 0, j, i, c, v, F.ph);
+        }
+      }
+    }
+}
+
+template <int CPL, int D, int NW, bool D0IN>
+static bool rbseq_fused_launch(hipStream_t st, const LevView *L, int nhelp, int rb, const RbFuse &F, int snapw) {
+  if constexpr (NW == 1 && D % RBF_CH == 0) {
+    const int per = 7 * RBF_WPB, octets = (F.nworkers + per - 1) / per, grid = 8 * (octets > nhelp + 2 ? octets : nhelp + 2);
+    const dim3 blk(WAVE * RBF_WPB);
+    if (snapw) { if (rb & 1) hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 1, true, 1, D0IN, 2>), dim3(grid), blk, 0, st, *L, nhelp, rb, F);
+                 else hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 0, true, 1, D0IN, 2>), dim3(grid), blk, 0, st, *L, nhelp, rb, F); }
+    else { if (rb & 1) hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 1, true, 1, D0IN, 1>), dim3(grid), blk, 0, st, *L, nhelp, rb, F);
+           else hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 0, true, 1, D0IN, 1>), dim3(grid), blk, 0, st, *L, nhelp, rb, F); }
+    return true;
+  } else return false;
+}
+
+// Do the workgroups 0, 8, 16 ... of a launch share an XCD (what the forwarding waves of the fused launch rely on)?  Asked once per device.
+__global__ void k_rbseq_xcc_probe(unsigned int *o) { if (threadIdx.x == 0) o[blockIdx.x] = rbs_xcc_id(); }
+static bool rbseq_placement_ok(hipStream_t st) {
+  static int known[64];   // per device: 0 = not asked yet, 1 = yes, 2 = no
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (known[dev]) return known[dev] == 1;
+  unsigned int *d = nullptr, h[256];
+  bool ok = hipMalloc((void **)&d, sizeof h) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_rbseq_xcc_probe, dim3(256), dim3(64), 0, st, d);
+    ok = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    for (int b = 8; ok && b < 256; b += 8) ok = h[b] == h[0];
+    (void)hipFree(d);
+  }
+  known[dev] = ok ? 1 : 2;
+  return ok;
+}
+
 extern "C" {
 
 void mgxk_rbseq_setup(hipStream_t st, const LevView *L) {
   hipLaunchKernelGGL(k_rbseq_setup, dim3((L->ny + 63) / 64, (L->nx + 3) / 4), dim3(64, 4), 0, st, *L);
 }
 
-// (b): d0 and the walk; returns 0 when the level has no instance (more than 1024 columns per half-row): the caller then runs the planes one by one
-int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
+// rows per correction wave: enough waves to fill the chip on the large levels, whole columns on the small ones
+static void rbseq_apply_shape(const LevView *L, int *ku, int *kr) {
+  const int nyh = L->ny / 2, nz = L->nz;
+  *ku = nz % 8 == 0 ? 8 : (nz % 4 == 0 ? 4 : 2);
+  *kr = nz;
+  const long long waves = (long long)((nyh + WAVE - 1) / WAVE) * L->nx;
+  while (*kr > *ku && *kr % 2 == 0 && (*kr / 2) % *ku == 0 && waves * (nz / *kr) < 4096) *kr /= 2;
+}
+
+// (b): d0 and the walk -- and, fz != nullptr, the correction (c) inside the walk's launch where an instance exists (returns 2 then).  Returns 0
+// when the level has no instance (more than 1024 columns per half-row): the caller then runs the planes one by one
+static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *fz, int snapw) {
   const int nyh = L->ny / 2, nx = L->nx;
   if (L->gk == nullptr || nyh > 16 * WAVE || (nx & 1)) return 0;
   static const bool two_waves = getenv("MGX_RBSEQ_TWO_WAVES") != nullptr, d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
@@ -249,13 +466,26 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
   if (nhelp > 32) nhelp = 32;
   if (nhelp > nx) nhelp = nx;
   if (help_env >= 0) nhelp = help_env < nx ? help_env : nx;
+  RbFuse none = {};
+  // the correction inside the walk's launch: instances for full half-rows, the deepest ring, nz a multiple of 8
+  int ku, kr;
+  rbseq_apply_shape(L, &ku, &kr);
+  // ... and where it pays: the correction of a colour is 24 B per cell; below ~100 MB it takes less than what the hand-off adds (the
+  // forwarding waves lag the walk by 2-5 us, the last workers finish ~4 us later: 256x256x32, 0.111 ms per sweep fused against 0.099)
+  const bool can_fuse = fz != nullptr && ku == 8 && kr <= 8 * RBF_NB && (long long)(nx + 2) * L->RS * 8 < (1LL << 31) && (long long)nx * nyh * L->nz >= fz->min_cells;
+  if (can_fuse) { fz->KR = kr; fz->nt = level_streams(L); fz->nchunk = (nyh + WAVE - 1) / WAVE; fz->nkz = L->nz / kr; fz->nworkers = nx * fz->nchunk * fz->nkz; }
+#define SCAN_LAUNCH(CPLV, DV, RBPV, FULLV, NWV, D0V, FUSEV, GRID, FARG)                                                \
+  hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, RBPV, FULLV, NWV, D0V, FUSEV>), dim3(GRID), dim3(WAVE * NWV), 0, st, *L, nhelp, rb, FARG)
 #define SCAN_CASE(CPLV, DV, FULLV, NWV, D0V)                                                                         \
-  { if (rbp) hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 1, FULLV, NWV, D0V>), dim3(1 + 8 * nhelp), dim3(WAVE * NWV), 0, st, *L, nhelp, rb); \
-    else hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, 0, FULLV, NWV, D0V>), dim3(1 + 8 * nhelp), dim3(WAVE * NWV), 0, st, *L, nhelp, rb);     \
+  { if (rbp) SCAN_LAUNCH(CPLV, DV, 1, FULLV, NWV, D0V, 0, 1 + 8 * nhelp, none); else SCAN_LAUNCH(CPLV, DV, 0, FULLV, NWV, D0V, 0, 1 + 8 * nhelp, none); \
     return 1; }
+  // fused: workgroup b holds 1 + RBF_NF workers unless b % 8 == 0 (those: the walk with its forwarding waves, the helpers, nothing)
+#define FUSE_CASE(CPLV, DV, NWV, D0V)                                                                                \
+  if (can_fuse && NWV == 1 && nyh == CPLV * WAVE && nx % DV == 0 && rbseq_fused_launch<CPLV, DV, NWV, D0V>(st, L, nhelp, rb, *fz, snapw)) return 2;
   // ring depth: D * (loads + stores per plane) < 63 (vmcnt), a divisor of nx
 #define SCAN_CPL(CPLV, DMAX, NWV, D0V)                                                                               \
   { const bool full = nyh == CPLV * WAVE * NWV;                                                                      \
+    FUSE_CASE(CPLV, DMAX, NWV, D0V)                                                                                  \
     if (nx % DMAX == 0) { if (full) SCAN_CASE(CPLV, DMAX, true, NWV, D0V) else SCAN_CASE(CPLV, DMAX, false, NWV, D0V) } \
     if (nx % 4 == 0) { if (full) SCAN_CASE(CPLV, 4, true, NWV, D0V) else SCAN_CASE(CPLV, 4, false, NWV, D0V) }       \
     if (full) SCAN_CASE(CPLV, 2, true, NWV, D0V) else SCAN_CASE(CPLV, 2, false, NWV, D0V) }
@@ -277,16 +507,33 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) {
   if (nyh <= 8 * WAVE) SCAN_CPL(8, 4, 1, false)
   SCAN_CPL(16, 2, 1, false)
 #undef SCAN_CPL
+#undef FUSE_CASE
 #undef SCAN_CASE
+#undef SCAN_LAUNCH
+}
+
+int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) { return rbseq_scan_launch(st, L, rb, nullptr, 0); }
+
+// (b) + (c) in one launch where an instance exists (returns 2), else (b) alone (returns 1: the caller launches mgxk_rbseq_apply) or nothing (0).
+// words: this level's hand-off words (device memory, zero at allocation: nx / 8 chunk words, the walk's progress word, 64 B apart);
+// seq: the number of this launch on the level (1, 2, ...: the caller counts); err: host-mapped error word; test_stall: the walk keeps
+// its progress to itself (the test of the bounded waits); min_cells: cells of a colour from which on the fused launch is used
+int mgxk_rbseq_scan_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, unsigned int *words, unsigned int seq, int *err, int test_stall, long long min_cells) {
+  RbFuse f = {};
+  f.ph = ph; f.flag = words; f.seq = seq; f.err = err; f.test_stall = test_stall; f.min_cells = min_cells;
+  if (L->nx >= (1 << 13) || err == nullptr || !rbseq_placement_ok(st)) return rbseq_scan_launch(st, L, rb, nullptr, 0);
+  return rbseq_scan_launch(st, L, rb, &f, snapw);
+}
+
+int mgxk_set_rbseq_timeout(double ms) {
+  const long long ticks = (long long)(ms * 1e5);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_rbs_timeout_ticks), &ticks, sizeof ticks) == hipSuccess ? 0 : 1;
 }
 
 void mgxk_rbseq_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw) {
   const int nyh = L->ny / 2, nz = L->nz;
-  const int ku = nz % 8 == 0 ? 8 : (nz % 4 == 0 ? 4 : 2);
-  // rows per wave: enough waves to fill the chip on the large levels, whole columns on the small ones
-  int kr = nz;
-  const long long waves = (long long)((nyh + WAVE - 1) / WAVE) * L->nx;
-  while (kr > ku && kr % 2 == 0 && (kr / 2) % ku == 0 && waves * (nz / kr) < 4096) kr /= 2;
+  int ku, kr;
+  rbseq_apply_shape(L, &ku, &kr);
   const dim3 grd((nyh + WAVE - 1) / WAVE, (L->nx + 3) / 4, nz / kr), blk(WAVE, 4);
   const int nt = level_streams(L);
 #define APPLY_CASE(KUV)                                                                                              \

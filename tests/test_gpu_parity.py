@@ -219,6 +219,84 @@ def test_relax_rb_sequential_order_at_speed(mg, dims, geom):
         assert np.abs(a - c).max() <= 1e-12 * np.abs(c).max(), (lev, np.abs(a - c).max() / np.abs(c).max())
 
 
+@pytest.mark.parametrize("dims", [(32, 512, 16), (64, 256, 32), (48, 128, 8)])
+def test_rb_sequential_order_correction_inside_the_walk_launch(mg, dims):
+    """Option "rbseq_fuse" (default 1, used from "rbseq_fuse_min" cells of a colour on -- set to 0 here so that small levels take it): the
+    per-column correction of the sequential-order red-black runs inside the launch of the walk over the planes, chasing it (workers on the
+    other XCDs, u handed over by forwarding waves: mgx_rbseq.hip, k_rbseq_scan FUSE).  The same bits as the correction in a launch of its
+    own, three sweeps per level from a rough random state, six repetitions (the hand-off is a cross-XCD publish: a stale read would show
+    as a different field in some repetition); one launch fewer per colour where an instance exists (half-rows of 64, 128, 256 columns);
+    and within 1e-12 of the oracle's sequential loop."""
+    nx, ny, nz = dims
+    o = _setup(mg, nx, ny, nz, "seamount", relax_method="RB")
+    rng = np.random.default_rng(37)
+    init = {}
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        init[lev] = (rng.standard_normal(g._shape("p")), rng.standard_normal(g._shape("b")))
+
+    def run(fuse):
+        mg.nhydro.set_option("rbseq_fuse", fuse)
+        out, launches = {}, {}
+        for lev in range(1, o.nlevs + 1):
+            g = mg.grid(lev)
+            g.set("p", init[lev][0]); g.set("b", init[lev][1]); mg.fill_halo(lev, "p")
+            n0 = mg.nhydro.counters()["launches"]
+            mg.relax(lev, 3)
+            launches[lev] = mg.nhydro.counters()["launches"] - n0
+            out[lev] = g.get("p")
+        return out, launches
+
+    try:
+        mg.nhydro.set_option("rbseq_fuse_min", 0)
+        ref, lref = run(0)
+        fused_levels = 0
+        for rep in range(6):
+            got, lgot = run(1)
+            for lev in ref:
+                assert np.array_equal(got[lev], ref[lev]), (rep, lev, np.abs(got[lev] - ref[lev]).max())
+            fused_levels = sum(1 for lev in ref if lgot[lev] == lref[lev] - 6)   # 3 sweeps x 2 colours, one launch fewer each
+        assert fused_levels >= 1, (lref, lgot)
+    finally:
+        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20)
+    lev = 1
+    o.field("p", lev)[...] = init[lev][0]; o.field("b", lev)[...] = init[lev][1]; o.fill_halo(lev, "p")
+    o.relax(lev, 3)
+    c = o.field("p", lev)
+    assert np.abs(ref[lev] - c).max() <= 1e-12 * np.abs(c).max()
+
+
+def test_rb_sequential_order_fused_launch_bounded_waits(mg):
+    """The waits inside the fused walk + correction launch are bounded: with the test hook "rbseq_test_stall" the walk keeps its progress
+    to itself, the forwarding waves give up after "rbseq_timeout_ms", release every word (the launch drains) and raise the error word:
+    the next synchronising call fails loudly and turns the fused launch off; the same call then runs with the correction in a launch
+    of its own and gives the sequential-order result."""
+    from mgroms_amd._lib import MgxError
+    nx, ny, nz = 32, 256, 16
+    o = _setup(mg, nx, ny, nz, "seamount", relax_method="RB")
+    rng = np.random.default_rng(43)
+    g = mg.grid(1)
+    p0 = rng.standard_normal(g._shape("p")); b0 = rng.standard_normal(g._shape("b"))
+    g.set("b", b0); g.set("p", p0); mg.fill_halo(1, "p")
+    o.field("p")[...] = p0; o.field("b")[...] = b0; o.fill_halo(1, "p")
+    o.relax(1, 2)
+    mg.nhydro.set_option("rbseq_fuse_min", 0)
+    mg.nhydro.set_option("rbseq_timeout_ms", 50)
+    mg.nhydro.set_option("rbseq_test_stall", 1)
+    try:
+        with pytest.raises(MgxError, match="lost its hand-off"):
+            mg.relax(1, 2)
+            g.get("p")
+        assert mg.nhydro.get_option("rbseq_fuse") == 0
+        g.set("p", p0); mg.fill_halo(1, "p")
+        mg.relax(1, 2)
+        c = o.field("p")
+        assert np.abs(g.get("p") - c).max() <= 1e-12 * np.abs(c).max()
+    finally:
+        mg.nhydro.set_option("rbseq_timeout_ms", 2000)
+        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20)
+
+
 @pytest.mark.parametrize("case", ["bmask", "tall", "stretched", "user_matrix"])
 def test_rb_sequential_order_other_coefficient_paths(mg, case):
     """The sequential-order red-black (default) where the colour pass runs other kernels / other coefficients than the seamount's matrix-free
