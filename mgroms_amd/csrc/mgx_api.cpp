@@ -36,8 +36,9 @@ int mgxk_relax_wave_fused(hipStream_t, const LevView *, const LevView *, int, in
 int mgxk_relax_gs_sweep(hipStream_t, const LevView *, int);
 void mgxk_snapshot_k1(hipStream_t, const LevView *);
 void mgxk_rbseq_setup(hipStream_t, const LevView *);
-int mgxk_rbseq_scan(hipStream_t, const LevView *, int);
-int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, unsigned int *, unsigned int, int *, int, long long);
+int mgxk_rbseq_scan(hipStream_t, const LevView *, int, int);
+int mgxk_rbseq_wants_d0(const LevView *);
+int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, int, unsigned int *, unsigned int, int *, int, long long);
 int mgxk_set_rbseq_timeout(double);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_has_reg_kernel(const LevView *);
@@ -193,6 +194,7 @@ struct State {
   int overlap = 0;       // option "overlap" / MGX_OVERLAP=1 (the same bits either way)
   long long n_overlap = 0;  // colour passes run that way
   int rbseq_fuse_min = 4 << 20;  // option "rbseq_fuse_min": cells of a colour (nx * ny/2 * nz) from which on the fused launch is used (below, the hand-off costs more than the correction's own launch: 256x256x32 0.111 ms per sweep fused, 0.099 separate)
+  int rbseq_d0_in_pass = 1;  // option "rbseq_d0_in_pass" (A/B): 0 = k_rbseq_d0 as a launch of its own
   int rbseq_test_stall = 0;  // test hook: the walk of the fused launch never reports its progress (the bounded waits must end the launch)
   int rbseq_fuse = 1;    // option "rbseq_fuse" / MGX_NO_RBSEQ_FUSE=1: the correction of the sequential-order red-black inside the walk's launch (k_rbseq_scan, FUSE) instead of a launch behind it (A/B)
   int use_chain = 1;     // option "restrict_chain" / MGX_NO_RESTRICT_CHAIN=1: Fcycle's first-leg restrictions below level 1 as one launch (A/B)
@@ -575,16 +577,21 @@ int relax(int lev, int nsweeps) {
         // seq on a closed level: the correction keeps the snapshot current (its colour's new bottom values and their physical images), so one
         // snapshot launch per relax call; with neighbours the halo part changes with every exchange
         if (S.real && !chain && !(seq && closed && !(it == 1 && rb == 1))) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
-        int fused = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
+        // (seq, wide half-rows: the pass also leaves the walk's d0 = y(k=1) - snapshot in u1 where its kernel can -- one launch less)
+        L.v.d0w = (seq && S.rbseq_d0_in_pass && mgxk_rbseq_wants_d0(&L.v)) ? L.v.u1 : nullptr;
+        const int pass = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
+        L.v.d0w = nullptr;
+        int fused = pass & 1;
+        const int have_d0 = (pass & 2) ? 1 : 0;
         if (seq) {
           // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
           // (where an instance exists the correction runs inside the walk's launch, chasing it: option "rbseq_fuse")
-          const int ran = S.rbseq_fuse ? mgxk_rbseq_scan_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0, L.rbs_flag, ++L.rbs_seq, S.kerr, S.rbseq_test_stall, (long long)S.rbseq_fuse_min) : mgxk_rbseq_scan(S.stream, &L.v, rb);
+          const int ran = S.rbseq_fuse ? mgxk_rbseq_scan_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0, have_d0, L.rbs_flag, ++L.rbs_seq, S.kerr, S.rbseq_test_stall, (long long)S.rbseq_fuse_min) : mgxk_rbseq_scan(S.stream, &L.v, rb, have_d0);
           if (ran == 2) S.rbseq_test_stall = 0;
           if (!ran) return fail("rb_seq: level %d (ny = %d) has no scan instance; set option rb_exact or rb_seq = 0", lev, L.ny);
           if (ran == 1) { mgxk_rbseq_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0); S.n_launch++; }
-          S.n_launch += 2;
+          S.n_launch += 2 - have_d0;
           fused = 1;  // the correction stores the physical images of every column it updates
         }
         CHK(fill_halo_js(L, L.v.p, fused));
@@ -1430,7 +1437,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     for (int q = 0; q < 2; q++) CHK(dmalloc(&L.zg_store[q], (size_t)(L.nx + 2) * L.v.RS));
     for (int q = 2; q < 4; q++) CHK(dmalloc(&L.zg_store[q], (size_t)L.nz + 1));
     L.v.dx2 = L.v.dy2 = nullptr; L.v.cffr = L.v.csr = nullptr;
-    L.v.gk = L.v.ag58 = L.v.u1 = nullptr;
+    L.v.gk = L.v.ag58 = L.v.u1 = nullptr; L.v.d0w = nullptr;
     if (S.method == M_RB && S.real) {  // sequential-order red-black (mgx_rbseq.hip): +8 B per cell
       CHK(dmalloc(&L.v.gk, L.n3js));
       CHK(dmalloc(&L.v.ag58, (size_t)2 * (L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
@@ -1689,6 +1696,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "ksp_test_stall")) S.ksp_test_stall = value;
   else if (streq(name, "rbseq_test_stall")) S.rbseq_test_stall = value;
   else if (streq(name, "rbseq_fuse_min")) S.rbseq_fuse_min = value;
+  else if (streq(name, "rbseq_d0_in_pass")) S.rbseq_d0_in_pass = value;
   else if (streq(name, "rbseq_timeout_ms")) { if (mgxk_set_rbseq_timeout((double)value)) return fail("rbseq_timeout_ms: could not set the device constant"); }
   else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
@@ -1728,6 +1736,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "restrict_chain")) *value = S.use_chain;
   else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
   else if (streq(name, "rbseq_fuse_min")) *value = S.rbseq_fuse_min;
+  else if (streq(name, "rbseq_d0_in_pass")) *value = S.rbseq_d0_in_pass;
   else if (streq(name, "overlap")) *value = S.overlap;
   else if (streq(name, "overlapped_passes")) *value = (int)S.n_overlap;
   else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;

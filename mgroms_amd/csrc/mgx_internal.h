@@ -18,6 +18,7 @@ struct LevView {
   double *gam;      // tridiag's `gam(k)` (mg_relax.f90:325)
   double *p1;       // snapshot of p(k=1,:,:) for the parallel red-black sweep, (nx+2) rows of RS
   double *p1w;      // when set: the colour pass also writes its new k=1 values here (= the snapshot of the NEXT sweep)
+  double *d0w;      // when set (sequential-order red-black, wide half-rows): the colour pass also writes y(k=1) - snapshot of its columns here (2-D, rows of RS): the scan's d0, no launch of its own
   double *zy, *zx;  // slopes ZY, ZX (JS layout) for the matrix-free cross terms; nullptr = use the stored slots
   // Interior rows of slots 4 and 7 rebuilt in the kernel (mg_define_matrix.f90:532-534,549-551) from the interface depths zw, and zw
   // itself from its generating formula (mg_zr_zw.f90:140-145): zw(k,j,i) = z0*h*hinv + zeta*(1.+z0*hinv), z0 = cffw(k) + csw(k)*h --

@@ -450,7 +450,7 @@ static void rbseq_apply_shape(const LevView *L, int *ku, int *kr) {
 
 // (b): d0 and the walk -- and, fz != nullptr, the correction (c) inside the walk's launch where an instance exists (returns 2 then).  Returns 0
 // when the level has no instance (more than 1024 columns per half-row): the caller then runs the planes one by one
-static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *fz, int snapw) {
+static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *fz, int snapw, int have_d0) {
   const int nyh = L->ny / 2, nx = L->nx;
   if (L->gk == nullptr || nyh > 16 * WAVE || (nx & 1)) return 0;
   static const bool two_waves = getenv("MGX_RBSEQ_TWO_WAVES") != nullptr, d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
@@ -494,7 +494,7 @@ static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *f
     if (nyh <= WAVE) SCAN_CPL(1, 16, 1, true)   // y, snapshot, the multiplier pair, the store of u: 4 operations per plane, 16 planes deep
     SCAN_CPL(2, 8, 1, true)
   }
-  hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
+  if (!have_d0) hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);   // (the colour pass may have written it: LevView::d0w)
   if (nyh <= WAVE) SCAN_CPL(1, 16, 1, false)
   if (nyh <= 2 * WAVE) SCAN_CPL(2, 16, 1, false)
   // wide half-rows: the requests of ONE wave (at most 63 in flight) do not cover the latency of a level that lives in HBM: several waves
@@ -512,17 +512,22 @@ static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *f
 #undef SCAN_LAUNCH
 }
 
-int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb) { return rbseq_scan_launch(st, L, rb, nullptr, 0); }
+int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb, int have_d0) { return rbseq_scan_launch(st, L, rb, nullptr, 0, have_d0); }
+// does the walk of this level read d0 from u1 (wide half-rows) rather than form it itself?  Then the colour pass should write it (LevView::d0w)
+int mgxk_rbseq_wants_d0(const LevView *L) {
+  static const bool d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
+  return L->gk != nullptr && (L->ny / 2 > 2 * WAVE || d0_out);
+}
 
 // (b) + (c) in one launch where an instance exists (returns 2), else (b) alone (returns 1: the caller launches mgxk_rbseq_apply) or nothing (0).
 // words: this level's hand-off words (device memory, zero at allocation: nx / 8 chunk words, the walk's progress word, 64 B apart);
 // seq: the number of this launch on the level (1, 2, ...: the caller counts); err: host-mapped error word; test_stall: the walk keeps
 // its progress to itself (the test of the bounded waits); min_cells: cells of a colour from which on the fused launch is used
-int mgxk_rbseq_scan_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, unsigned int *words, unsigned int seq, int *err, int test_stall, long long min_cells) {
+int mgxk_rbseq_scan_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, int have_d0, unsigned int *words, unsigned int seq, int *err, int test_stall, long long min_cells) {
   RbFuse f = {};
   f.ph = ph; f.flag = words; f.seq = seq; f.err = err; f.test_stall = test_stall; f.min_cells = min_cells;
-  if (L->nx >= (1 << 13) || err == nullptr || !rbseq_placement_ok(st)) return rbseq_scan_launch(st, L, rb, nullptr, 0);
-  return rbseq_scan_launch(st, L, rb, &f, snapw);
+  if (L->nx >= (1 << 13) || err == nullptr || !rbseq_placement_ok(st)) return rbseq_scan_launch(st, L, rb, nullptr, 0, have_d0);
+  return rbseq_scan_launch(st, L, rb, &f, snapw, have_d0);
 }
 
 int mgxk_set_rbseq_timeout(double ms) {

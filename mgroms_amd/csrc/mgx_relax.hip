@@ -212,6 +212,7 @@ __device__ __forceinline__ void relax_col_nz(const LevView &L, const int i, cons
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
   }
+  if (SNAP && L.d0w != nullptr) L.d0w[(long long)i * RS + c] = x[0] - L.p1[(long long)i * RS + c];  // mgx_rbseq.hip (b): d0, what k_rbseq_d0 would compute from the stored y
   if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry of this column (and its physical mirrors): no snapshot launch per pass
     // A mirrored halo cell is read (as a k=1 diagonal) only by columns of the OTHER colour, i.e. by the next pass of this
     // same sweep, which must see it updated: mirrors go to the buffer being read as well (no column of this pass reads them,
@@ -439,6 +440,7 @@ __device__ __forceinline__ void relax_col_mf(const LevView &L, const int i, cons
     if (mW) { p[oW + ro + c] = v; if (mS) p[oW + ro + cS] = v; if (mN) p[oW + ro + cN] = v; }
     if (mE) { p[oE + ro + c] = v; if (mS) p[oE + ro + cS] = v; if (mN) p[oE + ro + cN] = v; }
   }
+  if (SNAP && L.d0w != nullptr) L.d0w[(long long)i * RS + c] = x[0] - L.p1[(long long)i * RS + c];  // mgx_rbseq.hip (b): d0, what k_rbseq_d0 would compute from the stored y
   if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry of this column (and its physical mirrors): no snapshot launch per pass
     // A mirrored halo cell is read (as a k=1 diagonal) only by columns of the OTHER colour, i.e. by the next pass of this
     // same sweep, which must see it updated: mirrors go to the buffer being read as well (no column of this pass reads them,
@@ -837,17 +839,18 @@ int mgxk_relax_small(hipStream_t st, const LevView *L, int nsweeps, int method, 
 // returns 1 when the launched kernel also wrote the physical-boundary mirrors of p (no k_halo_phys needed)
 int mgxk_relax_ks(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);  // mgx_relax_ks.hip
 int mgxk_relax_nz128(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);  // mgx_relax_tall.hip
+// returns bit 0: the kernel stored the physical mirrors itself; bit 1: it wrote L->d0w
 int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
   if (mgxk_relax_ks(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return 1;  // mid levels: rows split over the waves of a workgroup
   switch (L->nz) {
 #ifndef MGX_QUICK  // -DMGX_QUICK: only the nz=64 instantiations (resource-usage checks of the level-1 kernel in seconds)
-    case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
-    case 4: launch_relax_nz<4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
-    case 8: launch_relax_nz<8>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
-    case 16: launch_relax_nz<16>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
-    case 32: launch_relax_nz<32>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
+    case 4: launch_relax_nz<4>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
+    case 8: launch_relax_nz<8>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
+    case 16: launch_relax_nz<16>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
+    case 32: launch_relax_nz<32>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
 #endif
-    case 64: launch_relax_nz<64>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return 1;
+    case 64: launch_relax_nz<64>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;
 #ifndef MGX_QUICK
     case 128: if (mgxk_relax_nz128(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return 1; break;
 #endif
