@@ -80,7 +80,7 @@ template <int N> struct VecD { double v[N]; };
 // write-through itself: vmcnt retires loads and stores in issue order, so every operand request would wait for the ~2.5 us a write-through
 // acknowledge takes (measured: 117 -> 320 ns per plane).  It stores u as before (acknowledged by its L2) and reports in a word of its own
 // how far it is -- plane i - D once step i has computed: the operands of step i were requested after u(i-D) was stored, and they are
-// back.  Four FORWARDING waves -- one workgroup of the walk's XCD (index a multiple of 8: the same L2), not of its compute unit (there
+// back.  Eight FORWARDING waves -- two workgroups of the walk's XCD (index a multiple of 8: the same L2), not of its compute unit (there
 // their write-through traffic slowed the walk from 54 to 82 us) -- take the chunks of RBF_CH planes in turn: wait for the chunk (sc1
 // poll of the progress word: served by the L2 the walk writes to), read its u past the L1 (sc1 loads), store it back write-through
 // (sc1), wait for every acknowledge (vmcnt(0)), then set the chunk's word (sc1 store of this launch's number).  The workers poll that
@@ -99,8 +99,9 @@ __device__ __forceinline__ void rbt_max(unsigned long long *a, unsigned long lon
 #else
 #define RBT(slot, op) {}
 #endif
-// forwarding waves, workers per workgroup, planes per chunk, words between two chunk words (64 B), batches of eight rows a worker holds at most
-constexpr int RBF_NF = 4, RBF_WPB = 4, RBF_CH = 8, RBF_FS = 16, RBF_NB = 4;
+// forwarding waves, workers per workgroup, planes per chunk, words between two chunk words (64 B), batches of eight rows a worker holds at most,
+// chunks between the walk and the workers that request their rows
+constexpr int RBF_NF = 8, RBF_WPB = 4, RBF_CH = 8, RBF_FS = 16, RBF_NB = 4, RBF_LEAD = 10;
 __device__ long long g_rbs_timeout_ticks = 200000000LL;  // 2 s of the 100 MHz clock (mgxk_set_rbseq_timeout shortens it for the test)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned int rbs_xcc_id() { return (unsigned int)__builtin_amdgcn_s_getreg(20 | (3 << 11)); }  // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -131,9 +132,21 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
     const bool live = wid < F.nworkers;
     const int w = live ? wid : F.nworkers - 1;
     const int kz = w % F.nkz, ch = (w / F.nkz) % F.nchunk, i = 1 + w / per;
+    // Pacing: the workgroups resident from the start (two per compute unit) would all request their rows at once -- tens of MB in front of
+    // the walk's first requests and its helpers' (measured: the helpers' first lines after 5.2 us, the walk's plane 33 after 10).  A worker
+    // asks for its rows when the word of the chunk RBF_LEAD before its own is set (the words trail the walk by ~5 us = 6 chunks: the walk
+    // is then ~4 chunks away, the rows take ~2.5 us to arrive), the first ones after ~1.5 us + half the time the walk needs to get there.
+    {
+      const int cl = il > 1 ? (il - 2) / RBF_CH - RBF_LEAD : -1;
+      if (threadIdx.x < 64) {
+        if (cl >= 0) { if (!rbs_wait<32>(F.flag + cl * RBF_FS, F.seq) && threadIdx.x == 0) *F.err = 2; }
+        else { __builtin_amdgcn_s_sleep(60); for (int k = 0; k < (il >> 2); k++) __builtin_amdgcn_s_sleep(8); }   // ~1.5 us + 0.05 us per plane
+      }
+      __syncthreads();
+    }
+    if (wid == F.nworkers - 1 && (threadIdx.x & 63) == 0) RBT(3, rbt_set)
     // plane 0 is halo: u = 0 there, always
     rbseq_worker<FUSE == 2>(L, rb, F, ch * WAVE + (int)(threadIdx.x & 63), i, kz, live, il > 1 ? F.flag + ((il - 2) / RBF_CH) * RBF_FS : nullptr);
-    if (live && (threadIdx.x & 63) == 0) RBT(7, rbt_max)
     return;
   }
   if (FUSE && blockIdx.x == 0) {
@@ -141,9 +154,10 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
     if (threadIdx.x == 0) F.flag[(L.nx / RBF_CH) * RBF_FS + 1] = (F.seq << 4) | rbs_xcc_id();
     if (threadIdx.x == 0) RBT(0, rbt_set)
   }
-  if (FUSE && blockIdx.x == 8u * (nhelp + 1)) {
-    // the forwarding waves
-    const int f = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (FUSE && (blockIdx.x == 8u * (nhelp + 1) || blockIdx.x == 8u * (nhelp + 2))) {
+    // the forwarding waves (two workgroups: a chunk takes a wave ~4 us -- poll, read, write through, acknowledge -- and the walk finishes one
+    // every 0.86 us; with four waves the words fell 5-9 us behind by the end of the walk)
+    const int f = (int)(threadIdx.x >> 6) + (blockIdx.x == 8u * (nhelp + 1) ? 0 : RBF_WPB), lane = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(L.u1, 0, 0x7fffffff, 0x00020000);
     constexpr int LPP = CPL >= 2 ? CPL / 2 : 1;   // 16-byte requests per lane and plane (half-row = CPL * 64 columns)
     const unsigned int *pw = F.flag + (L.nx / RBF_CH) * RBF_FS;
@@ -184,21 +198,42 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
     if ((blockIdx.x & 7) != 0) return;
     const int h = (blockIdx.x >> 3) - 1;
     if (h >= nhelp) return;   // (a fused launch has more workgroups on this XCD than helpers)
-    // planes h+1, h+1+nhelp, ...: the helpers' front advances in the walk's order, nhelp planes at a time
-    const int nyh_ = L.ny >> 1;
-    double acc = 0.0;
-    for (int i = 1 + h; i <= L.nx; i += nhelp) {
-      const int off = rb_jodd(i, rb) ? L.HO : L.EO + 1;
-      const long long q = (long long)i * L.RS + off;
-      for (int t = threadIdx.x * 2; t < nyh_; t += 2 * (int)blockDim.x) {   // 16-byte requests; a half-row is a multiple of 2 columns and starts 16-byte aligned
-        double2 a, b, c, d;
-        if (D0IN) { __builtin_memcpy(&a, L.p + (long long)i * L.plane + off + t, 16); __builtin_memcpy(&b, L.p1 + q + t, 16); }
-        else { __builtin_memcpy(&a, L.u1 + q + t, 16); b = a; }
-        __builtin_memcpy(&c, L.ag58 + 2 * (q + t), 16); __builtin_memcpy(&d, L.ag58 + 2 * (q + t) + 2, 16);
-        acc += a.x + b.y + c.x + d.y;
+    // Helper h takes the planes [h*per+1, (h+1)*per] and touches every 64 bytes of their operand rows ONCE, all requests in flight
+    // before the first is waited for.  (The workgroups of a launch start ~0.15 us apart; a helper that walked its planes one after the
+    // other, a memory latency each, left the walk right behind the helpers' start-up for its first planes: plane 33 after 7.8 us.)
+    const int nyh_ = L.ny >> 1, per = (L.nx + nhelp - 1) / nhelp, ia = 1 + h * per, ib = ia + per - 1 < L.nx ? ia + per - 1 : L.nx;
+    const int seg = (nyh_ * 8 + 63) / 64, ppp = seg * (D0IN ? 4 : 3), total = (ib - ia + 1) * ppp;   // 64-byte pieces: an 8-byte-per-column row has seg of them
+    float acc = 0.f;
+    for (int t0 = threadIdx.x; t0 < total; t0 += 8 * (int)blockDim.x) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int t = t0 + e * (int)blockDim.x;
+        v[e] = 0.f;
+        if (t < total) {
+          const int i = ia + t / ppp, r = t % ppp, off = rb_jodd(i, rb) ? L.HO : L.EO + 1;
+          const long long q = (long long)i * L.RS + off;
+          const char *base;
+          int piece = r;
+          if (D0IN) {
+            if (r < seg) base = (const char *)(L.p + (long long)i * L.plane + off);
+            else if (r < 2 * seg) { base = (const char *)(L.p1 + q); piece = r - seg; }
+            else { base = (const char *)(L.ag58 + 2 * q); piece = r - 2 * seg; }
+          } else {
+            if (r < seg) base = (const char *)(L.u1 + q);
+            else { base = (const char *)(L.ag58 + 2 * q); piece = r - seg; }
+          }
+          // (the last piece of a row is clamped to the row's last 4 bytes)
+          const int rowbytes = (r < (D0IN ? 2 : 1) * seg ? 8 : 16) * nyh_;
+          int byte = piece * 64;
+          if (byte > rowbytes - 4) byte = rowbytes - 4;
+          v[e] = *(const float *)(base + byte);
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc += v[e];
     }
-    if (acc == 1.2345678e-301) L.u1[0] = acc;   // never: keeps the requests alive (row 0 of u1 is halo and stays zero)
+    if (acc == 1.2345678e-30f) L.u1[0] = acc;   // never: keeps the requests alive (row 0 of u1 is halo and stays zero)
     return;
   }
   const int lane = threadIdx.x & 63, wv = FUSE ? 0 : threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
@@ -244,7 +279,7 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
   for (int d = 0; d < D; d++) { LOADP(1 + d, d) asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }  // slot by slot, as the loop issues them: the waits at the loop head are the minimum of both orders
   for (int i0 = 1; i0 <= nx; i0 += D) {
 #ifdef MGX_RBSEQ_TRACE
-    if (FUSE && lane == 0) { if (i0 == 1 + nx / 4) RBT(3, rbt_set) if (i0 == 1 + nx / 2) RBT(4, rbt_set) if (i0 == 1) RBT(5, rbt_set) if (i0 == 1 + 32) RBT(6, rbt_set) }
+
 #endif
 #pragma unroll
     for (int d = 0; d < D; d++) {
@@ -293,7 +328,6 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
   }
 #undef LOADP
   if (FUSE) {
-    if (lane == 0) RBT(1, rbt_set)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && !F.test_stall) F.flag[(nx / RBF_CH) * RBF_FS] = (F.seq << 13) + (unsigned int)nx;
   }
@@ -379,9 +413,16 @@ __device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbF
   if (threadIdx.x < 64 && word != nullptr && !rbs_wait<16>(word, F.seq) && threadIdx.x == 0) *F.err = 2;
   __syncthreads();
   if (!live) return;
+#ifdef MGX_RBSEQ_TRACE
+  const bool lastw = i == L.nx && kz == F.nkz - 1 && jh == (L.ny >> 1) - 64;
+  if (lastw) RBT(4, rbt_set)
+#endif
   const double ujp = __hip_atomic_load(L.u1 + qm + jp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double ujm = __hip_atomic_load(L.u1 + qm + jm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double s = 0.0 - c5 * ujp - c8 * ujm;
+#ifdef MGX_RBSEQ_TRACE
+  if (lastw) { if (s == 1.234e-300) L.u1[0] = s; RBT(5, rbt_set) }
+#endif
 #pragma unroll
   for (int b = 0; b < RBF_NB; b++)
     if (b < nb) {
@@ -399,12 +440,15 @@ __device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbF
         }
       }
     }
+#ifdef MGX_RBSEQ_TRACE
+  if (lastw) RBT(1, rbt_set)
+#endif
 }
 
 template <int CPL, int D, int NW, bool D0IN>
 static bool rbseq_fused_launch(hipStream_t st, const LevView *L, int nhelp, int rb, const RbFuse &F, int snapw) {
   if constexpr (NW == 1 && D % RBF_CH == 0) {
-    const int per = 7 * RBF_WPB, octets = (F.nworkers + per - 1) / per, grid = 8 * (octets > nhelp + 2 ? octets : nhelp + 2);
+    const int per = 7 * RBF_WPB, octets = (F.nworkers + per - 1) / per, grid = 8 * (octets > nhelp + 3 ? octets : nhelp + 3);
     const dim3 blk(WAVE * RBF_WPB);
     if (snapw) { if (rb & 1) hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 1, true, 1, D0IN, 2>), dim3(grid), blk, 0, st, *L, nhelp, rb, F);
                  else hipLaunchKernelGGL((k_rbseq_scan<CPL, D, 0, true, 1, D0IN, 2>), dim3(grid), blk, 0, st, *L, nhelp, rb, F); }
@@ -472,7 +516,10 @@ static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *f
   rbseq_apply_shape(L, &ku, &kr);
   // ... and where it pays: the correction of a colour is 24 B per cell; below ~100 MB it takes less than what the hand-off adds (the
   // forwarding waves lag the walk by 2-5 us, the last workers finish ~4 us later: 256x256x32, 0.111 ms per sweep fused against 0.099)
-  const bool can_fuse = fz != nullptr && ku == 8 && kr <= 8 * RBF_NB && (long long)(nx + 2) * L->RS * 8 < (1LL << 31) && (long long)nx * nyh * L->nz >= fz->min_cells;
+  const bool can_fuse = fz != nullptr && ku == 8 && (long long)(nx + 2) * L->RS * 8 < (1LL << 31) && (long long)nx * nyh * L->nz >= fz->min_cells;
+  // eight rows per worker there: what a worker does after its word is set -- 16 stores with the mirrors, ~1.4 us per eight rows under load --
+  // is the tail of the launch behind the walk's last plane (level-1 sweep at 512x512x64 with 32 / 16 / 8 rows: 0.346 / 0.345-0.357 / 0.339 ms)
+  if (can_fuse) kr = 8;
   if (can_fuse) { fz->KR = kr; fz->nt = level_streams(L); fz->nchunk = (nyh + WAVE - 1) / WAVE; fz->nkz = L->nz / kr; fz->nworkers = nx * fz->nchunk * fz->nkz; }
 #define SCAN_LAUNCH(CPLV, DV, RBPV, FULLV, NWV, D0V, FUSEV, GRID, FARG)                                                \
   hipLaunchKernelGGL((k_rbseq_scan<CPLV, DV, RBPV, FULLV, NWV, D0V, FUSEV>), dim3(GRID), dim3(WAVE * NWV), 0, st, *L, nhelp, rb, FARG)

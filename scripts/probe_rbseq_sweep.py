@@ -22,6 +22,6 @@ if os.environ.get("MGX_TRACE"):
     nhydro.time_relax(1, 1)
     lib.mgx_debug_rbs(1, buf)
     t = list(buf); t0 = t[0]
-    names = ["walk_start", "walk_loop_end", "last_forward", "walk_quarter", "walk_half", "walk_loop_start", "walk_plane33", "workers_end_max"]
+    names = ["walk_start", "lastw_stores_issued", "last_forward", "lastw_gate1", "lastw_flag", "lastw_u", "lastw_batch0_issued", "workers_end_max"]
     print({n: (round((v - t0) / 100.0, 2) if v else None) for n, v in zip(names, t)}, "us (last colour pass of the sweep)")
 mg.nhydro_clean()
