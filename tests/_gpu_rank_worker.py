@@ -20,6 +20,7 @@ def main():
     par = "par" in opts            # relax_method='RB' as the plain parallel sweep (rb_seq = 0); default: the sequential order at speed (rb_seq = 1)
     golden = "golden" in opts      # namelist defaults, compared with the reference's recorded 2x2 history (tests/golden)
     rndtopo = "rndtopo" in opts    # mg_testrndtopo's geometry (BASELINE config 4) instead of the seamount
+    fuse0 = "fuse0" in opts        # red-black, sequential order: the correction inside the walk's launch on every level that has an instance (rbseq_fuse_min = 0), open sides included
     connectfail = "connectfail" in opts  # rank 1 cannot open its neighbours' buffers (test hook): everybody must end up on the hooks, and every norm's all-reduce must carry the same count on all ranks
     if connectfail:
         os.environ["MGX_P2P_TEST_FAIL_CONNECT"] = "1"
@@ -48,6 +49,8 @@ def main():
     par = nhydro.default_params(relax_method=method, solver_prec=tol, nsmall=nsmall, ns_coarsest=nsc, bmask=1 if bmask else 0)
     nhydro.set_option("rb_exact", 1 if exact else 0)
     nhydro.set_option("rb_seq", 0 if par else 1)
+    if fuse0:
+        nhydro.set_option("rbseq_fuse_min", 0)
     nhydro.set_option("overlap", 1)   # the exchange beside the interior sweep (off by default: slower on a shared GPU); the bits must not depend on it
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     stamp("init")

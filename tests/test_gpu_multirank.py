@@ -31,6 +31,7 @@ def _free_port():
     (2, 1, 32, 32, 16, 8, "RB"),    # red-black, the default: the reference's sequential order per rank (scan + rank-one correction, mgx_rbseq.hip) to 1e-10
     (2, 2, 32, 32, 16, 32, "RB"),   # the same on 2x2 with every coarse level gathered
     (2, 2, 32, 32, 16, 8, "RB+golden"),  # the reference default against its recorded, decomposition-dependent 2x2 history to 1e-10 -- without rb_exact
+    (2, 1, 32, 128, 16, 8, "RB+fuse0"),  # ... with the correction inside the walk's launch on an OPEN level (half-rows of 64 columns, one neighbour): two ranks' fused launches share the card
     (2, 1, 32, 32, 16, 8, "RB+par"),  # the plain parallel sweep (rb_seq = 0): history within 5e-5 of the oracle
     (2, 1, 64, 128, 64, 8, "FC"),   # nz=64: the level-1 kernels of the bench (matrix-free, 3-deep pipeline) with an open side
     (2, 2, 32, 32, 16, 8, "FC+nop2p"), # the exchange callback (torch.distributed) instead of the peer-to-peer pushes
