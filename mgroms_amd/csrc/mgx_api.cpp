@@ -38,6 +38,7 @@ void mgxk_snapshot_k1(hipStream_t, const LevView *);
 void mgxk_rbseq_setup(hipStream_t, const LevView *);
 int mgxk_rbseq_scan(hipStream_t, const LevView *, int, int);
 int mgxk_rbseq_wants_d0(const LevView *);
+int mgxk_rbseq_walk_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, int, unsigned int *, unsigned int, int *, int, long long);
 int mgxk_set_rbseq_timeout(double);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
@@ -586,6 +587,12 @@ int relax(int lev, int nsweeps) {
         if (seq) {
           // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
+          // small levels whose pass left d0 in u1: walk and correction in one launch, every workgroup walking for itself (k_rbseq_walk_apply)
+          if (have_d0 && S.rbseq_fuse && mgxk_rbseq_walk_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0)) {
+            S.n_launch++; fused = 1;
+            CHK(fill_halo_js(L, L.v.p, fused));
+            continue;
+          }
           // (where an instance exists the correction runs inside the walk's launch, chasing it: option "rbseq_fuse")
           const int ran = S.rbseq_fuse ? mgxk_rbseq_scan_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0, have_d0, L.rbs_flag, ++L.rbs_seq, S.kerr, S.rbseq_test_stall, (long long)S.rbseq_fuse_min) : mgxk_rbseq_scan(S.stream, &L.v, rb, have_d0);
           if (ran == 2) S.rbseq_test_stall = 0;

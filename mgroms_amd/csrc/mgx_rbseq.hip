@@ -445,6 +445,81 @@ __device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbF
 #endif
 }
 
+// (b) + (c) of a SMALL level in one launch without any hand-off: every workgroup walks the planes 1 .. ib-1 itself (wave 0, u into LDS),
+// then its four waves correct the planes ia .. ib it owns (rows split over the waves).  The walk of such a level is a few microseconds of
+// dependent steps on operands that live in the L2 / Infinity Cache; redoing it in ~64 workgroups costs no time -- the launch lasts as
+// long as the longest walk plus one correction -- and saves the correction's launch and the kernel boundary in front of it (levels 3 and
+// 4 of the 512x512x64 problem: 10.5 + 5 and 7.6 + 5 us in two launches).  d0 must come from a buffer no workgroup of this launch writes
+// (the colour pass left it in u1: LevView::d0w): another workgroup may already be correcting p and the snapshot of a plane this one
+// still walks over.  Half-rows of at most 64 columns (one column per lane), at most 128 planes (u: 74 KB of LDS).
+template <int D, int RBP, bool SNAPW>
+__global__ __launch_bounds__(256) void k_rbseq_walk_apply(LevView L, int rb, Sides ph, int PB, int nt) {
+  extern __shared__ double ul[];   // u(jh, plane) at plane * 64 + jh; plane 0 (halo) and the lanes past the half-row: zero
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1, nx = L.nx;
+  const int ia = blockIdx.x * PB + 1, ib = ia + PB - 1 < nx ? ia + PB - 1 : nx;
+  const int nwalk = ib - 1;
+  if (threadIdx.x < 64) ul[threadIdx.x] = 0.0;
+  if (wv == 0 && nwalk >= 1) {
+    const bool ok = lane < nyh;
+    const int jc = ok ? lane : nyh - 1;
+    const long long RS = L.RS;
+    const double *__restrict__ d0 = L.u1, *__restrict__ g58 = L.ag58;
+    double rd[D], ra[D], rbb[D], up = 0.0;
+#define WLOADP(ip, slot)                                                                                         \
+    {                                                                                                            \
+      const int i_ = (ip) <= nx ? (ip) : nx;                                                                     \
+      const long long q_ = (long long)i_ * RS + (((((slot) + 1 + RBP) & 1) == 0) ? L.HO : L.EO + 1) + jc;        \
+      rd[slot] = d0[q_]; ra[slot] = g58[2 * q_]; rbb[slot] = g58[2 * q_ + 1];                                    \
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) { WLOADP(1 + d, d) asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    for (int i0 = 1; i0 <= nwalk; i0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int i = i0 + d;
+        const bool jodd = (((d + 1 + RBP) & 1) == 0);  // = rb_jodd(i, rb): i0 is odd, D even
+        const double edge = jodd ? wave_shr1(up) : wave_shl1(up);
+        const double ua = jodd ? up : edge, ub = jodd ? edge : up;   // u(j+1,i-1), u(j-1,i-1)
+        double t = __builtin_fma(-ra[d], ua, rd[d]);
+        t = __builtin_fma(-rbb[d], ub, t);
+        up = ok ? t : 0.0;
+        ul[i * 64 + lane] = up;
+        WLOADP(i + D, d)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef WLOADP
+  }
+  __syncthreads();
+  if (lane >= nyh) return;
+  const int R = L.nz >> 2, k0 = wv * R;   // rows of this wave
+  double *__restrict__ p = L.p;
+  const double *__restrict__ g = L.gk;
+  for (int i = ia; i <= ib; i++) {
+    const int jh = lane, jodd = rb_jodd(i, rb);
+    const int c = jodd ? L.HO + jh : L.EO + jh + 1;
+    const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
+    // odd j: u(j+1,i-1) is the previous plane's jh, u(j-1,i-1) its jh - 1; even j: jh + 1 and jh (zero beyond the half-row: halo)
+    const double *um = ul + (i - 1) * 64;
+    const double ujp = jodd ? um[jh] : (jh + 1 < nyh ? um[jh + 1] : 0.0);
+    const double ujm = jodd ? (jh > 0 ? um[jh - 1] : 0.0) : um[jh];
+    const long long o = (long long)i * L.plane;
+    const double s = 0.0 - L.cA[4][o + c] * ujp - L.cA[7][o + c] * ujm;
+    for (int t = 0; t < R; t++) {
+      const int k = k0 + t;
+      const long long ro = (long long)k * L.RS;
+      const double v = p[o + ro + c] + ld_rt(g + o + ro + c, nt) * s;
+      p[o + ro + c] = v;
+      mirror_store(L, p, ro, j, i, c, v, ph);
+      if (SNAPW && k == 0) {
+        LevView L2 = L; L2.plane = L.RS;  // the snapshot: one row per plane
+        L.p1[(long long)i * L.RS + c] = v;
+        mirror_store(L2, L.p1, 0, j, i, c, v, ph);
+      }
+    }
+  }
+}
+
 template <int CPL, int D, int NW, bool D0IN>
 static bool rbseq_fused_launch(hipStream_t st, const LevView *L, int nhelp, int rb, const RbFuse &F, int snapw) {
   if constexpr (NW == 1 && D % RBF_CH == 0) {
@@ -563,7 +638,8 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb, int have_d0) { ret
 // does the walk of this level read d0 from u1 (wide half-rows) rather than form it itself?  Then the colour pass should write it (LevView::d0w)
 int mgxk_rbseq_wants_d0(const LevView *L) {
   static const bool d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
-  return L->gk != nullptr && (L->ny / 2 > 2 * WAVE || d0_out);
+  // (wide half-rows: the walk reads d0; small levels: k_rbseq_walk_apply needs it where no workgroup of its launch writes)
+  return L->gk != nullptr && (L->ny / 2 > 2 * WAVE || d0_out || (L->ny / 2 <= WAVE && L->nx <= 128));
 }
 
 // (b) + (c) in one launch where an instance exists (returns 2), else (b) alone (returns 1: the caller launches mgxk_rbseq_apply) or nothing (0).
@@ -575,6 +651,31 @@ int mgxk_rbseq_scan_apply(hipStream_t st, const LevView *L, int rb, Sides ph, in
   f.ph = ph; f.flag = words; f.seq = seq; f.err = err; f.test_stall = test_stall; f.min_cells = min_cells;
   if (L->nx >= (1 << 13) || err == nullptr || !rbseq_placement_ok(st)) return rbseq_scan_launch(st, L, rb, nullptr, 0, have_d0);
   return rbseq_scan_launch(st, L, rb, &f, snapw, have_d0);
+}
+
+// (b) + (c) of a small level in ONE launch (k_rbseq_walk_apply); needs d0 in u1 (the colour pass wrote it).  Returns 1 when launched.
+int mgxk_rbseq_walk_apply(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw) {
+  const int nyh = L->ny / 2, nx = L->nx, nz = L->nz;
+  static const bool off = getenv("MGX_NO_RBSEQ_WALK_APPLY") != nullptr;
+  if (off || L->gk == nullptr || nyh > WAVE || nx > 128 || (nx & 1) || nz < 4 || (nz & 3)) return 0;
+  mgx_before_launch();
+  constexpr int DW = 16;
+  const size_t lds = (size_t)(nx + DW + 1) * 64 * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    const int mx = (128 + DW + 1) * 64 * (int)sizeof(double);
+    if (hipFuncSetAttribute((const void *)k_rbseq_walk_apply<DW, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_rbseq_walk_apply<DW, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_rbseq_walk_apply<DW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_rbseq_walk_apply<DW, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    attr = true;
+  }
+  const int pb = nx > 64 ? (nx + 63) / 64 : 1, nblk = (nx + pb - 1) / pb, nt = level_streams(L);
+  if (snapw) { if (rb & 1) hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 1, true>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt);
+               else hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 0, true>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt); }
+  else { if (rb & 1) hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 1, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt);
+         else hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 0, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt); }
+  return mgx_launched();
 }
 
 int mgxk_set_rbseq_timeout(double ms) {

@@ -841,7 +841,7 @@ int mgxk_relax_ks(hipStream_t, const LevView *, int, int, int, int, int, int, in
 int mgxk_relax_nz128(hipStream_t, const LevView *, int, int, int, int, int, int, int, Sides);  // mgx_relax_tall.hip
 // returns bit 0: the kernel stored the physical mirrors itself; bit 1: it wrote L->d0w
 int mgxk_relax_colour(hipStream_t st, const LevView *L, int i0, int istep, int nplanes, int jodd_fixed, int rb, int real, int snap, Sides ph) {
-  if (mgxk_relax_ks(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return 1;  // mid levels: rows split over the waves of a workgroup
+  if (const int ks = mgxk_relax_ks(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph)) return ks;  // mid levels: rows split over the waves of a workgroup
   switch (L->nz) {
 #ifndef MGX_QUICK  // -DMGX_QUICK: only the nz=64 instantiations (resource-usage checks of the level-1 kernel in seconds)
     case 2: launch_relax_nz<2>(st, L, i0, istep, nplanes, jodd_fixed, rb, real, snap, ph); return (real && snap && L->d0w != nullptr) ? 3 : 1;

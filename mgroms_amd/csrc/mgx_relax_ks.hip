@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_relax_ks(LevView L, int i0, int 
     for (int k = NZ - 1; k >= 1; k--) x[k - 1] = x[k - 1] - g[k] * x[k];
 #pragma unroll
     for (int k = 1; k <= NZ; k++) sh[(k - 1) * WAVE + lane] = x[k - 1];
+    if (SNAP && L.d0w != nullptr) L.d0w[(long long)i * RS + c] = x[0] - L.p1[(long long)i * RS + c];  // mgx_rbseq.hip (b): the walk's d0
     if (SNAP && L.p1w != nullptr) {  // next sweep's k=1 snapshot entry and its physical mirrors (see relax_col_nz)
       const int j = jodd ? 2 * jh + 1 : 2 * jh + 2;
       const bool mS = ph.S && j == 1, mN = ph.N && j == L.ny, mW = ph.W && i == 1, mE = ph.E && i == L.nx;
@@ -599,7 +600,7 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
   {                                                                                                                              \
     dim3 blk(WAVE, NWV);                                                                                                         \
     const size_t lds = (size_t)3 * NZV * WAVE * sizeof(double);                                                                  \
-    if (real && snap) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, true>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);   \
+    if (real && snap) { hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, true>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx); return mgx_launched() ? (L->d0w != nullptr ? 3 : 1) : 0; } \
     else if (real) hipLaunchKernelGGL((k_relax_ks<NZV, NWV, true, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);     \
     else hipLaunchKernelGGL((k_relax_ks<NZV, NWV, false, false>), grd, blk, lds, st, *L, i0, istep, nplanes, jodd_fixed, rb, ph, gx);              \
     return mgx_launched();                                                                                                       \
@@ -624,6 +625,7 @@ int mgxk_relax_ks(hipStream_t st, const LevView *L, int i0, int istep, int nplan
 #undef KS_LAUNCH
 }
 
+// (mgxk_relax_ks returns 0 = not launched, 1 = launched, 3 = launched and L->d0w written)
 // both colours of the planes i0, i0+2, ... of a four-colour sweep in one launch; returns 1 when launched (closed level, one column set per plane)
 int mgxk_relax_ks_pair(hipStream_t st, const LevView *L, int i0, int nplanes, int real, Sides ph) {
   mgx_before_launch();
