@@ -452,6 +452,9 @@ __device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbF
 // 4 of the 512x512x64 problem: 10.5 + 5 and 7.6 + 5 us in two launches).  d0 must come from a buffer no workgroup of this launch writes
 // (the colour pass left it in u1: LevView::d0w): another workgroup may already be correcting p and the snapshot of a plane this one
 // still walks over.  Half-rows of at most 64 columns (one column per lane), at most 128 planes (u: 74 KB of LDS).
+// Measured and dropped: the same with two columns per lane and u of the workgroup's own planes only (any number of planes), to serve
+// level 2 (256 planes of 128 columns) as well: Vcycle 3.52 against 3.19 ms with level 2 included (128 workgroups each redoing a 20 us
+// walk), and 3.24 against 3.19 on levels 3-4 alone (the generic walk is slower than this one).
 template <int D, int RBP, bool SNAPW>
 __global__ __launch_bounds__(256) void k_rbseq_walk_apply(LevView L, int rb, Sides ph, int PB, int nt) {
   extern __shared__ double ul[];   // u(jh, plane) at plane * 64 + jh; plane 0 (halo) and the lanes past the half-row: zero

@@ -225,8 +225,9 @@ def test_rb_sequential_order_correction_inside_the_walk_launch(mg, dims):
     per-column correction of the sequential-order red-black runs inside the launch of the walk over the planes, chasing it (workers on the
     other XCDs, u handed over by forwarding waves: mgx_rbseq.hip, k_rbseq_scan FUSE).  The same bits as the correction in a launch of its
     own, three sweeps per level from a rough random state, six repetitions (the hand-off is a cross-XCD publish: a stale read would show
-    as a different field in some repetition); one launch fewer per colour where an instance exists (half-rows of 64, 128, 256 columns);
-    and within 1e-12 of the oracle's sequential loop."""
+    as a different field in some repetition); one launch fewer per colour where an instance exists (half-rows of 256 columns; with
+    half-rows of at most 64 columns and at most 128 planes the same option selects k_rbseq_walk_apply instead: every workgroup redoes the walk up to its planes
+    and corrects them, no hand-off -- the third shape and the coarse levels of the others); and within 1e-12 of the oracle's sequential loop."""
     nx, ny, nz = dims
     o = _setup(mg, nx, ny, nz, "seamount", relax_method="RB")
     rng = np.random.default_rng(37)
@@ -272,7 +273,7 @@ def test_rb_sequential_order_fused_launch_bounded_waits(mg):
     the next synchronising call fails loudly and turns the fused launch off; the same call then runs with the correction in a launch
     of its own and gives the sequential-order result."""
     from mgroms_amd._lib import MgxError
-    nx, ny, nz = 32, 256, 16
+    nx, ny, nz = 32, 512, 16     # half-rows of 256 columns: the level-1 walk with forwarding waves and workers
     o = _setup(mg, nx, ny, nz, "seamount", relax_method="RB")
     rng = np.random.default_rng(43)
     g = mg.grid(1)
