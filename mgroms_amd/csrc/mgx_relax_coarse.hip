@@ -34,6 +34,13 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
   // seq (the walk below): Q4 = per column the quad {d0 (then s) of the colour in work, cA(5,1), cA(8,1), g(1)} -- one 32-byte read per
   // plane step -- plus one all-zero quad (index PL) for the lanes past the half-row; GK = g = T^-1 e1 of every column (set once)
   double *__restrict__ Q4 = ldsw + (NZ + 1) * PL, *__restrict__ GK = Q4 + 4 * (PL + 1);
+  // register walk (one-wave instance, nz = 2, at most RWN planes: the coarsest level of the 512x512x64 hierarchy, 16x16x2): the three constants
+  // of a plane step stay in registers for the whole call and d0 / s cross between the column owners and the walk lanes through DS, one row
+  // per walk lane (DS[jh * RWP + i - 1]): 16-byte LDS accesses, two planes each, instead of a 32-byte quad per plane and an 8-byte store
+  constexpr int RWN = 16, RWP = RWN + 2;
+  constexpr bool rwc = seq && NZ == 2 && NT == 64;
+  double *__restrict__ DS = GK + NZ * PL;
+  const bool rw = rwc && nx <= RWN;
   const int lane = threadIdx.x;
   // 32-bit element offsets (these levels have a few thousand cells): base pointer in scalar registers + one 32-bit byte offset per load
   // (the 64-bit index arithmetic of ~200 loads per lane and the divisions of a flat cell index were most of this kernel's fixed cost)
@@ -130,6 +137,18 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
   if (seq && threadIdx.x < 4) Q4[4 * PL + threadIdx.x] = 0.0;
   const bool walk_on = REAL && seq && method == 1;
   __syncthreads();
+  // register walk: (cA5, cA8, g1) of the lane's column in every plane, for either colour (planes past nx and lanes past the half-row: zeros -> u = 0)
+  double k5[rwc ? 2 : 1][rwc ? RWN : 1], k8[rwc ? 2 : 1][rwc ? RWN : 1], kg[rwc ? 2 : 1][rwc ? RWN : 1];
+  if (rwc && rw && walk_on) {
+#pragma unroll
+    for (int c_ = 0; c_ < 2; c_++)
+#pragma unroll
+      for (int d_ = 0; d_ < RWN; d_++) {
+        const bool jo_ = ((d_ & 1) == 0) == (c_ == 0);   // plane d_ + 1 holds the colour's odd j
+        const int oc_ = (lane < (ny >> 1) && d_ < nx) ? d_ * W + 2 * lane + (jo_ ? 0 : 1) : PL;
+        k5[c_][d_] = Q4[4 * oc_ + 1]; k8[c_][d_] = Q4[4 * oc_ + 2]; kg[c_][d_] = Q4[4 * oc_ + 3];
+      }
+  }
 #define R3(q, k) (((q) & 1) ? xj[(q) >> 1][0][k] : a3[((q) + 1) & 3][k])
 #define R4(q, k) (((q) & 1) ? xj[(q) >> 1][1][k] : a4[((q) + 1) & 3][k])
 #define R5(q, k) (((q) & 1) ? xj[(q) >> 1][2][k] : a5[((q) + 1) & 3][k])
@@ -175,7 +194,8 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
     /* gam(k) = dd(k-1)*bet(k-1) (mg_relax.f90:325): the same product as the stored pivot table, recomputed */              \
     _Pragma("unroll") for (int k = NZ - 2; k >= 0; k--) x[k] = x[k] - (a2[q][k + 1] * bet[q][k]) * x[k + 1];                \
     _Pragma("unroll") for (int k = 0; k < NZ; k++) P[k * PL + oc] = x[k];                                                   \
-    if (walk_on) Q4[4 * oc] = x[0] - P1[oc];   /* d0 of the walk */                                                         \
+    if (walk_on) { const double d0_ = x[0] - P1[oc];   /* d0 of the walk */                                                 \
+      if (rw) DS[((j - 1) >> 1) * RWP + (i - 1)] = d0_; else Q4[4 * oc] = d0_; }                                            \
   }
   for (int it = 0; it < nsweeps; it++) {
     if (method == 2) {  // four colours (mg_relax.f90:212-230): (i odd,j odd), (i odd,j even), (i even,j odd), (i even,j even)
@@ -216,13 +236,26 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
 #define WALK_APPLY(q)                                                                                                        \
       {                                                                                                                       \
         const int oc_ = (2 * bi + ((q) >> 1)) * W + 2 * bj + ((q) & 1);                                                       \
-        const double s_ = Q4[4 * oc_];                                                                                        \
+        const double s_ = rw ? DS[(bj) * RWP + 2 * bi + ((q) >> 1)] : Q4[4 * oc_];   /* column (i,j) = (2bi+1+(q>>1), 2bj+1+(q&1)): jh = bj */ \
         _Pragma("unroll") for (int k = 0; k < NZ; k++) P[k * PL + oc_] = P[k * PL + oc_] + GK[k * PL + oc_] * s_;              \
+        P1[oc_] = P[oc_];   /* the snapshot stays current: no copy of the level in front of the next pass */                  \
       }
       // RBV = 1: odd planes hold the colour's odd j (QA = 0), even planes its even j (QB = 3); RBV = 2: the other way round (QA = 1, QB = 2)
 #define SEQ_WALK(QA, QB, RBV)                                                                                                \
       if (REAL && seq) {                                                                                                      \
-        if (threadIdx.x < 64) {                                                                                               \
+        if (rwc && rw) {                                                                                                      \
+          double dv[RWN], up = 0.0;                                                                                           \
+          _Pragma("unroll") for (int d_ = 0; d_ < RWN; d_ += 2) __builtin_memcpy(&dv[d_], DS + lane * RWP + d_, 16);           \
+          _Pragma("unroll") for (int d_ = 0; d_ < RWN; d_++) {                                                                \
+            const bool jo_ = ((d_ & 1) == 0) == ((RBV) == 1);                                                                 \
+            const double sh_ = jo_ ? wave_shr1(up) : wave_shl1(up);                                                           \
+            const double ua_ = jo_ ? up : sh_, ub_ = jo_ ? sh_ : up;                                                          \
+            const double s_ = __builtin_fma(-k8[RBV - 1][d_], ub_, -(k5[RBV - 1][d_] * ua_));                                 \
+            up = __builtin_fma(kg[RBV - 1][d_], s_, (d_ < nx && lane < (ny >> 1)) ? dv[d_] : 0.0);                            \
+            dv[d_] = s_;                                                                                                      \
+          }                                                                                                                   \
+          _Pragma("unroll") for (int d_ = 0; d_ < RWN; d_ += 2) __builtin_memcpy(DS + lane * RWP + d_, &dv[d_], 16);           \
+        } else if (threadIdx.x < 64) {                                                                                        \
           const bool wact = lane < (ny >> 1);                                                                                 \
           const int jA = 2 * lane;                                                                                            \
           double up = 0.0;                                                                                                    \
@@ -239,11 +272,12 @@ __global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, in
         if (mine) { WALK_APPLY(QA) WALK_APPLY(QB) }                                                                           \
         __syncthreads();                                                                                                      \
       }
-      if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
+      // (walk_on: the correction keeps the snapshot current -- a pass reads and changes entries of its own colour only -- one copy per call)
+      if (REAL && !(walk_on && it > 0)) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(0) COLUMN(3) }   // rb = 1: j = 1+mod(i+1,2): (i odd, j odd) and (i even, j even)
       __syncthreads();
       SEQ_WALK(0, 3, 1)
-      if (REAL) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
+      if (REAL && !walk_on) { for (int t = lane; t < PL; t += NT) P1[t] = P[t]; __syncthreads(); }
       if (mine) { COLUMN(1) COLUMN(2) }   // rb = 2
       __syncthreads();
       SEQ_WALK(1, 2, 2)
@@ -344,7 +378,7 @@ static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int 
   if ((nblk > WAVE || L->nz == 4) && off4) return 0;
   size_t bytes = ((size_t)L->nz + 1) * (L->nx + 2) * (L->ny + 2) * sizeof(double);
   if (seq) {  // p, the snapshot and u, interiors only
-    bytes = ((2 * (size_t)L->nz + 5) * L->nx * L->ny + 4) * sizeof(double);  // p, the snapshot, the operand quads (+ a zero quad), g
+    bytes = ((2 * (size_t)L->nz + 5) * L->nx * L->ny + 4 + 64 * 18) * sizeof(double);  // p, the snapshot, the operand quads (+ a zero quad), g, the register walk's d0 / s rows
     if (bytes > 160 * 1024) return 0;
   }
   const LevView Cc = Cv ? *Cv : *L;
