@@ -349,6 +349,9 @@ def main():
         also_rb["exact_order"] = {"sweep_ms": nhydro.time_relax(1, 1), "tolerance": "bit-identical to the reference's sequential loop (one launch per plane: a parity mode)"}
         nhydro.set_option("rb_exact", 0); nhydro.set_option("rb_seq", 1)
         also_rb["sweep_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["sweep_ms"] / also_rb["parallel"]["sweep_ms"]
+        also_rb["vcycle_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["ms_per_step"] / also_rb["parallel"]["ms_per_step"]
+        also_rb["sequential_order"]["how"] = ("per colour: parallel pass (writes the walk's d0), then the walk over the planes with the per-column correction chasing it inside the "
+                                              "same launch (level 1: forwarding waves + workers on the other XCDs; levels 3-4: every workgroup walks for itself); DESIGN.md 4.4")
 
     # HBM traffic of the dominant kernel from the PMC counters: they cannot be collected inside this run (rocprofv3 must wrap
     # the process, in passes of their own), so the figure is read from the committed capture of THIS command
