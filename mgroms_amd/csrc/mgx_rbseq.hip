@@ -615,7 +615,10 @@ static int rbseq_scan_launch(hipStream_t st, const LevView *L, int rb, RbFuse *f
     if (nx % 4 == 0) { if (full) SCAN_CASE(CPLV, 4, true, NWV, D0V) else SCAN_CASE(CPLV, 4, false, NWV, D0V) }       \
     if (full) SCAN_CASE(CPLV, 2, true, NWV, D0V) else SCAN_CASE(CPLV, 2, false, NWV, D0V) }
   // small half-rows: one wave forms d0 itself (the level lives in L2; the walk is bound by its dependent chain, not by its requests)
-  if (nyh <= 2 * WAVE && !d0_out) {
+  // (half-rows of 65..128 columns whose pass wrote d0: the walk reads it -- three requests and a store per plane, 16 planes of look-ahead
+  // instead of 8 with five: level 2 of 512x512x64 20.5 -> ~16 us per colour, Vcycle 3.12 -> 3.08 ms; MGX_RBSEQ_NO_D0_MID: A/B)
+  static const bool d0_mid = getenv("MGX_RBSEQ_NO_D0_MID") == nullptr;
+  if (nyh <= 2 * WAVE && !d0_out && !(have_d0 && d0_mid && nyh > WAVE)) {
     if (nyh <= WAVE) SCAN_CPL(1, 16, 1, true)   // y, snapshot, the multiplier pair, the store of u: 4 operations per plane, 16 planes deep
     SCAN_CPL(2, 8, 1, true)
   }
@@ -642,7 +645,8 @@ int mgxk_rbseq_scan(hipStream_t st, const LevView *L, int rb, int have_d0) { ret
 int mgxk_rbseq_wants_d0(const LevView *L) {
   static const bool d0_out = getenv("MGX_RBSEQ_D0_KERNEL") != nullptr;
   // (wide half-rows: the walk reads d0; small levels: k_rbseq_walk_apply needs it where no workgroup of its launch writes)
-  return L->gk != nullptr && (L->ny / 2 > 2 * WAVE || d0_out || (L->ny / 2 <= WAVE && L->nx <= 128));
+  static const bool d0_mid = getenv("MGX_RBSEQ_NO_D0_MID") == nullptr;
+  return L->gk != nullptr && (L->ny / 2 > 2 * WAVE || d0_out || (L->ny / 2 <= WAVE && L->nx <= 128) || (d0_mid && L->ny / 2 > WAVE));
 }
 
 // (b) + (c) in one launch where an instance exists (returns 2), else (b) alone (returns 1: the caller launches mgxk_rbseq_apply) or nothing (0).
