@@ -117,7 +117,7 @@ __device__ __forceinline__ bool rbs_wait(const unsigned int *word, unsigned int 
   }
 }
 template <bool SNAPW>
-__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, const unsigned int *word);
+__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, int c_lo, int c_hi);
 
 template <int CPL, int D, int RBP, bool FULL, int NW, bool D0IN, int FUSE>
 __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(LevView L, int nhelp, int rb, RbFuse F) {
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(FUSE ? 64 * RBF_WPB : 64 * NW) void k_rbseq_scan(Le
     }
     if (wid == F.nworkers - 1 && (threadIdx.x & 63) == 0) RBT(3, rbt_set)
     // plane 0 is halo: u = 0 there, always
-    rbseq_worker<FUSE == 2>(L, rb, F, ch * WAVE + (int)(threadIdx.x & 63), i, kz, live, il > 1 ? F.flag + ((il - 2) / RBF_CH) * RBF_FS : nullptr);
+    // the chunks that hold plane i-1 of the workgroup's first and last worker (the words are set by different forwarding waves, in no
+    // particular order: a workgroup whose workers lie on either side of a chunk boundary waits for both)
+    const int i1 = 1 + wid0 / per;
+    rbseq_worker<FUSE == 2>(L, rb, F, ch * WAVE + (int)(threadIdx.x & 63), i, kz, live, i1 > 1 ? (i1 - 2) / RBF_CH : 0, il > 1 ? (il - 2) / RBF_CH : -1);
     return;
   }
   if (FUSE && blockIdx.x == 0) {
@@ -386,10 +389,10 @@ __global__ __launch_bounds__(256) void k_rbseq_apply(LevView L, int rb, Sides ph
 // (c) as a worker of the fused launch (k_rbseq_scan, FUSE): the same arithmetic as rbseq_apply_cols.  What does not depend on the walk -- y
 // and g of the worker's rows (at most 32: four batches of eight), the two couplings -- is requested BEFORE the wait for the walk, so a
 // worker that has waited finishes one memory latency after its word is set (the tail of the launch behind the walk's last plane).
-// `word` (wave 0 of the workgroup polls it, the others wait at the barrier): the chunk of plane i-1 of the workgroup's LAST worker;
+// c_lo .. c_hi (wave 0 of the workgroup polls their words, the others wait at the barrier): the chunks that hold plane i-1 of the workgroup's workers;
 // every load of u is an sc1 load.
 template <bool SNAPW>
-__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, const unsigned int *word) {
+__device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbFuse &F, int jh, int i, int kz, bool live, int c_lo, int c_hi) {
   const int jodd = rb_jodd(i, rb);
   int c, jm, jp;
   if (jodd) { c = L.HO + jh; jm = L.EO + jh; jp = jm + 1; }
@@ -410,7 +413,9 @@ __device__ __forceinline__ void rbseq_worker(const LevView &L, int rb, const RbF
         for (int t = 0; t < 8; t++) { const long long ko = o + (long long)(k0 + 8 * b + t) * L.RS + c; pv[b][t] = p[ko]; gv[b][t] = ld_rt(g + ko, nt); }
       }
   }
-  if (threadIdx.x < 64 && word != nullptr && !rbs_wait<16>(word, F.seq) && threadIdx.x == 0) *F.err = 2;
+  if (threadIdx.x < 64)
+    for (int c_ = c_lo; c_ <= c_hi; c_++)
+      if (!rbs_wait<16>(F.flag + c_ * RBF_FS, F.seq) && threadIdx.x == 0) *F.err = 2;
   __syncthreads();
   if (!live) return;
 #ifdef MGX_RBSEQ_TRACE
@@ -683,6 +688,24 @@ int mgxk_rbseq_walk_apply(hipStream_t st, const LevView *L, int rb, Sides ph, in
   else { if (rb & 1) hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 1, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt);
          else hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 0, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt); }
   return mgx_launched();
+}
+
+// MGX_CHECK_P1 (debugging aid): how many entries of the k = 1 snapshot differ from p(k = 1) -- whole rows, halo columns and halo planes included
+__global__ void k_rbseq_check_snap(LevView L, int *bad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (t >= L.RS) return;
+  const double a = L.p1[(long long)i * L.RS + t], b = L.p[(long long)i * L.plane + t];
+  if (!(a == b)) atomicAdd(bad, 1);
+}
+int mgxk_rbseq_check_snap(hipStream_t st, const LevView *L) {
+  int *d = nullptr, h = -1;
+  if (hipMalloc((void **)&d, sizeof(int)) != hipSuccess) return -1;
+  (void)hipMemsetAsync(d, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_rbseq_check_snap, dim3((unsigned)((L->RS + 255) / 256), L->nx + 2), dim3(256), 0, st, *L, d);
+  (void)hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(d);
+  return h;
 }
 
 int mgxk_set_rbseq_timeout(double ms) {
