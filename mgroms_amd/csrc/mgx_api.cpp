@@ -41,7 +41,6 @@ int mgxk_rbseq_wants_d0(const LevView *);
 int mgxk_rbseq_walk_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, int, unsigned int *, unsigned int, int *, int, long long);
 int mgxk_set_rbseq_timeout(double);
-int mgxk_rbseq_check_snap(hipStream_t, const LevView *);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
@@ -54,7 +53,7 @@ int mgxk_residual_restrict(hipStream_t, const LevView *, const LevView *, double
 int mgxk_residual_restrict_ex(hipStream_t, const LevView *, const LevView *, double *, int real, Sides, double *zero, double *partial, double *dup);
 int mgxk_residual_restrict_grid(const LevView *, const LevView *);
 void mgxk_reduce(hipStream_t, const double *, int, double *);
-int mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int, int);
+void mgxk_coarse2fine(hipStream_t, const LevView *, const LevView *, const double *, int, Sides, int, int);
 void mgxk_divc_selftest(hipStream_t, const double *, const double *, int, unsigned long long *);
 void mgxk_halo_phys(hipStream_t, const LevView *, double *, Sides);
 void mgxk_halo_mixed_corners(hipStream_t, const LevView *, double *, int, int, int, int);
@@ -129,7 +128,6 @@ struct Level {
   size_t p2p_goff[2];           // gathered levels: ngroup blocks of the peer-to-peer gather, by parity
   unsigned long long p2p_gseq = 0;
   unsigned int *ksp_done = nullptr; unsigned int ksp_seq = 0;  // per-plane progress counters of the persistent mid-level relax (k_relax_ksp) and their common value
-  unsigned long long p1_gen = 0;  // the C-ABI call during which the k = 1 snapshot p1 was left equal to p(k = 1) (0: not)
   unsigned int *rbs_flag = nullptr; unsigned int rbs_seq = 0;  // progress word of the sequential-order red-black walk and the number of its launches (mgx_rbseq.hip: k_rbseq_scan, FUSE)
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
@@ -196,10 +194,7 @@ struct State {
   // ~50 us), so the chain exchange -> boundary part -> exchange is no shorter than the serial one; the two cross-stream waits per colour come on top.
   int overlap = 0;       // option "overlap" / MGX_OVERLAP=1 (the same bits either way)
   long long n_overlap = 0;  // colour passes run that way
-  long long n_snap_checked = 0;  // MGX_CHECK_P1: snapshots left by transfer kernels that were compared with p(k=1)
   int rbseq_fuse_min = 4 << 20;  // option "rbseq_fuse_min": cells of a colour (nx * ny/2 * nz) from which on the fused launch is used (below, the hand-off costs more than the correction's own launch: 256x256x32 0.111 ms per sweep fused, 0.099 separate)
-  unsigned long long gen = 1;  // number of the C-ABI call in progress
-  int rbseq_snap_in_transfers = 1;  // option "rbseq_snap_in_transfers" (A/B): the prolongation / the restriction's zeroing of the coarse p also write the k = 1 snapshot of the relax call that follows
   int rbseq_d0_in_pass = 1;  // option "rbseq_d0_in_pass" (A/B): 0 = k_rbseq_d0 as a launch of its own
   int rbseq_test_stall = 0;  // test hook: the walk of the fused launch never reports its progress (the bounded waits must end the launch)
   int rbseq_fuse = 1;    // option "rbseq_fuse" / MGX_NO_RBSEQ_FUSE=1: the correction of the sequential-order red-black inside the walk's launch (k_rbseq_scan, FUSE) instead of a launch behind it (A/B)
@@ -247,8 +242,7 @@ int fail(const char *fmt, ...) {
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define CHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
-// (S.gen: one number per call of the C ABI -- what a transfer kernel leaves for the next relax of the SAME call, see p1_leave / p1_left)
-#define NEED_INIT() do { if (!S.inited) return fail("mgx_init has not been called"); S.gen++; } while (0)
+#define NEED_INIT() do { if (!S.inited) return fail("mgx_init has not been called"); } while (0)
 #define NEED_LEV(l) do { NEED_INIT(); if ((l) < 1 || (l) > S.nlevs) return fail("level %d out of range 1..%d", (l), S.nlevs); } while (0)
 
 int dmalloc(double **p, size_t n) {
@@ -532,20 +526,8 @@ struct TicScope { int lev; const char *name; TicScope(int l, const char *n) : le
 
 // ---- operators ------------------------------------------------------------------------------------
 // mg_relax.f90:16-47 relax ; :151-190 RB ; :193-234 FC
-// Sequential-order red-black on a closed level: the k = 1 snapshot p1 of a relax call equals p(k = 1) at the start of the call.  The kernel that
-// wrote p last inside the SAME C-ABI call may have left it (coarse2fine: the corrected values; the restriction that zeroes the coarse p:
-// zeros; a sequential-order relax: its correction keeps it current) -- then the snapshot launch is skipped.  Anything else that writes p says so.
-static inline void p1_leave(Level &L, bool ok) { L.p1_gen = ok ? S.gen : 0; }
-static inline bool p1_left(const Level &L) { return L.p1_gen == S.gen; }
-static inline bool p1_wanted(const Level &L) {   // would relax(lev) of this level use a snapshot the transfers can leave?
-  const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
-  return S.rbseq_snap_in_transfers && S.method == M_RB && S.real && S.rb_seq && !S.rb_exact && L.v.gk != nullptr && all_physical(ph) && !S.tictoc;
-}
-
 int relax(int lev, int nsweeps) {
   Level &L = S.lev[lev - 1];
-  const bool snap_left = p1_left(L);
-  p1_leave(L, false);
   TicScope ts(lev, S.method == M_RB ? "relax_3D_8_RB" : (S.method == M_FC ? "relax_3D_8_FC" : "relax_3D_8_GS"));  // mg_relax.f90:128,167,209
   if (S.tictoc && S.tt_done.size() > 4096) tt_collect();
   if (S.method == M_GS) {  // exact lexicographic order by hyperplanes; halo fill once per sweep (mg_relax.f90:131-141)
@@ -595,11 +577,7 @@ int relax(int lev, int nsweeps) {
       for (int rb = 1; rb <= 2; rb++) {
         // seq on a closed level: the correction keeps the snapshot current (its colour's new bottom values and their physical images), so one
         // snapshot launch per relax call; with neighbours the halo part changes with every exchange
-        if (S.real && !chain && !(seq && closed && !(it == 1 && rb == 1)) && !(seq && closed && snap_left)) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
-        else if (seq && closed && snap_left && it == 1 && rb == 1) {
-          static const bool check = getenv("MGX_CHECK_P1") != nullptr;
-          if (check) { const int bad = mgxk_rbseq_check_snap(S.stream, &L.v); if (bad) return fail("MGX_CHECK_P1: level %d, %d entries of the snapshot a transfer kernel left differ from p(k=1)", lev, bad); S.n_snap_checked++; }
-        }
+        if (S.real && !chain && !(seq && closed && !(it == 1 && rb == 1))) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
         // (seq, wide half-rows: the pass also leaves the walk's d0 = y(k=1) - snapshot in u1 where its kernel can -- one launch less)
         L.v.d0w = (seq && S.rbseq_d0_in_pass && mgxk_rbseq_wants_d0(&L.v)) ? L.v.u1 : nullptr;
         const int pass = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
@@ -626,7 +604,6 @@ int relax(int lev, int nsweeps) {
         CHK(fill_halo_js(L, L.v.p, fused));
       }
       if (chain) { L.v.p1 = L.v.p1w; L.v.p1w = nullptr; if (it == nsweeps) L.v.p1 = p1a; }
-      if (seq && closed && it == nsweeps) p1_leave(L, true);   // the corrections kept the snapshot current
     } else {
       // A level with neighbours, halos by the pushes: the boundary part of a colour (the waves that hold a column next to a neighbour's
       // halo -- what the exchange sends, and all that reads what the last exchange delivered) and the exchange behind it go to a second
@@ -697,14 +674,10 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
   if (!C.gather) {
     // closed level: the kernel also zeroes p_c and, for Fcycle, duplicates b_c into r_c (whole arrays through the mirrors)
     fused = all_physical(phc);
-    LevView Cz = C.v;
-    Cz.d0w = (fused && p1_wanted(C)) ? C.v.p1 : nullptr;   // the fused residual + restriction also zeroes the snapshot's rows
-    const int d = down(&Cz, C.v.b, phc, fused ? C.v.p : nullptr);
+    const int d = down(&C.v, C.v.b, phc, fused ? C.v.p : nullptr);
     if (d < 0) return 1;
     if (!d) { mgxk_fine2coarse(S.stream, &F.v, &C.v, C.v.b, phc, fused && dup_r ? C.v.r : nullptr, fused ? C.v.p : nullptr); S.n_launch++; }
-    p1_leave(C, d == 1 && Cz.d0w != nullptr);
   } else {
-    p1_leave(C, false);
     const int d = down(&C.vs, C.vs.b, none, nullptr);
     if (d < 0) return 1;
     if (!d) { mgxk_fine2coarse(S.stream, &F.v, &C.vs, C.vs.b, none, nullptr, nullptr); S.n_launch++; }
@@ -753,12 +726,8 @@ int fine2coarse(int lev, bool dup_r = false, bool with_residual = false) {
 int coarse2fine(int lev, bool keep_r = true, bool skip1 = false) {
   Level &F = S.lev[lev - 1], &C = S.lev[lev];
   const Sides phf = {F.neighb[0] < 0, F.neighb[1] < 0, F.neighb[2] < 0, F.neighb[3] < 0};
-  p1_leave(F, false);
   if (!C.gather) {
-    LevView Fz = F.v;
-    Fz.d0w = (!keep_r && !skip1 && S.linear && p1_wanted(F)) ? F.v.p1 : nullptr;   // k_coarse2fine_run<false,false> also writes the snapshot of the relax that follows
-    const int wrote = mgxk_coarse2fine(S.stream, &Fz, &C.v, C.v.p, S.linear, phf, keep_r, skip1 && !keep_r); S.n_launch++;
-    p1_leave(F, wrote && Fz.d0w != nullptr);
+    mgxk_coarse2fine(S.stream, &F.v, &C.v, C.v.p, S.linear, phf, keep_r, skip1 && !keep_r); S.n_launch++;
   } else {
     mgxk_split(S.stream, &C.v, &C.vs, C.v.p, C.vs.p, C.key % 2, C.key / 2); S.n_launch++;
     mgxk_coarse2fine(S.stream, &F.v, &C.vs, C.vs.p, S.linear, phf, keep_r, skip1 && !keep_r); S.n_launch++;
@@ -782,7 +751,6 @@ int relax_fused(int lev, int nsweeps, int flags) {
   if (!all_physical(phf) || !all_physical(phc) || C.gather) return 0;
   if (!mgxk_relax_wave_fused(S.stream, &F.v, &C.v, nsweeps, S.method, S.real, phf, flags, mode)) return 0;
   S.n_launch++;
-  p1_leave(F, false); p1_leave(C, false);
   if (flags & 1) F.r_halo_stale = true;  // what coarse2fine leaves (the correction is not stored in r inside a cycle)
   return 1;
 }
@@ -829,7 +797,6 @@ int fcycle(bool have_r2 = false) {
       Level &C = S.lev[1];
       HIPCHK(hipMemcpyAsync(C.v.b, C.v.r, C.n3js * sizeof(double), hipMemcpyDeviceToDevice, S.stream));   // physical images included (the kernel stored them)
       HIPCHK(hipMemsetAsync(C.v.p, 0, C.n3js * sizeof(double), S.stream));
-      p1_leave(C, false);
       C.b_halo_stale = true; S.n_launch += 2;
       continue;
     }
@@ -845,7 +812,6 @@ int fcycle(bool have_r2 = false) {
         if (dep >= 2 && F.nx % (1 << dep) == 0 && F.ny % (1 << dep) == 0 && F.nz % (1 << dep) == 0) {
           const Sides all = {1, 1, 1, 1};
           mgxk_restrict_chain(S.stream, vs, dep, all); S.n_launch++;
-          for (int q = 1; q <= dep; q++) p1_leave(S.lev[lev - 1 + q], false);   // their p is zeroed, not their snapshot
           lev += dep - 1;
           continue;
         }
@@ -903,7 +869,6 @@ int solve_p(double tol, int maxite, int *nite_out, double *res_out, double *hist
   TicScope ts(1, "solve");  // mg_solvers.f90:45
   const auto tstart = std::chrono::steady_clock::now();  // cpu_time(tstart) (:46); wall clock here, the work is on the GPU
   if (!S.warm_start) HIPCHK(hipMemsetAsync(L.v.p, 0, L.n3js * sizeof(double), S.stream));  // grid(1)%p = 0 (:35)
-  p1_leave(L, false);
   mgxk_sumsq(S.stream, &L.v, L.v.b, S.d_partial, S.d_scalar); S.n_launch += 2;
   double bnorm; CHK(global_sum(L, &bnorm)); bnorm = sqrt(bnorm);
   int nite = 0;
@@ -1739,7 +1704,6 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "rbseq_test_stall")) S.rbseq_test_stall = value;
   else if (streq(name, "rbseq_fuse_min")) S.rbseq_fuse_min = value;
   else if (streq(name, "rbseq_d0_in_pass")) S.rbseq_d0_in_pass = value;
-  else if (streq(name, "rbseq_snap_in_transfers")) S.rbseq_snap_in_transfers = value;
   else if (streq(name, "rbseq_timeout_ms")) { if (mgxk_set_rbseq_timeout((double)value)) return fail("rbseq_timeout_ms: could not set the device constant"); }
   else if (streq(name, "ksp_timeout_ms")) { if (mgxk_set_ksp_timeout((double)value)) return fail("ksp_timeout_ms: could not set the device constant"); }
   else if (streq(name, "p2p_test_drop")) S.p2p_test_drop = value;
@@ -1780,10 +1744,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
   else if (streq(name, "rbseq_fuse_min")) *value = S.rbseq_fuse_min;
   else if (streq(name, "rbseq_d0_in_pass")) *value = S.rbseq_d0_in_pass;
-  else if (streq(name, "rbseq_snap_in_transfers")) *value = S.rbseq_snap_in_transfers;
   else if (streq(name, "overlap")) *value = S.overlap;
   else if (streq(name, "overlapped_passes")) *value = (int)S.n_overlap;
-  else if (streq(name, "snapshots_checked")) *value = (int)S.n_snap_checked;
   else if (streq(name, "ksp")) *value = (S.use_ksp && !S.ksp_down) ? 1 : 0;
   else if (streq(name, "async")) *value = S.async_ops;
   else if (streq(name, "fuse_tail")) *value = S.use_fuse;

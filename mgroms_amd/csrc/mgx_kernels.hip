@@ -475,9 +475,7 @@ __global__ __launch_bounds__(256) void k_coarse2fine_run(LevView F, LevView C, c
     const long long ro_ = (long long)((k)-1) * F.RS, t_ = OO_ + ro_ + PP_; const double v_ = (val), w_ = pc[4 * half + (Q)] + v_;                     \
     if (WR) st_rt(rf + t_, v_, stream); st_rt(pf + t_, w_, stream);                                                                                    \
     const int jf_ = ((Q) & 1) ? 2 * j2 : 2 * j2 - 1, if_ = ((Q) & 2) ? i + 1 : i;                                                                      \
-    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP_, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP_, w_, ph);                                         \
-    /* F.d0w set (sequential-order red-black, closed level): the k = 1 snapshot of the relax call that follows, no launch for it */                    \
-    if (!WR && !SK && F.d0w != nullptr && (k) == 1) { LevView F2_ = F; F2_.plane = F.RS; F.d0w[(long long)if_ * F.RS + PP_] = w_; mirror_store(F2_, F.d0w, 0, jf_, if_, PP_, w_, ph); } }
+    if (WR) mirror_store(F, rf, ro_, jf_, if_, PP_, v_, ph); mirror_store(F, pf, ro_, jf_, if_, PP_, w_, ph); }
   const bool edge0 = (ph.S && j2 == 1) || (ph.W && i2 == 1);  // SK: the (i odd, j odd) column of this lane is read through a mirror
   const int ce = lane == 0 ? cm : (lane == WAVE - 1 ? cp : c0);
   const int pol = live ? po : F.HO + (C.ny - 1), pel = live ? pe : F.EO + C.ny;  // columns the loads of a lane past the row fall on
@@ -899,8 +897,7 @@ void mgxk_fine2coarse(hipStream_t st, const LevView *F, const LevView *C, double
   hipLaunchKernelGGL(k_fine2coarse, grd, dim3(WAVE, 4), 0, st, *F, *C, dst, ph, level_streams(F), dup, zero, KC);
 }
 // skip1: the caller guarantees that a four-colour relax of the fine level follows (cycles only; see k_coarse2fine_run, SK)
-// returns 1 when the kernel that ran honours F->d0w (writes the k = 1 snapshot of the fine level beside p), else 0
-int mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r, int skip1) {
+void mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const double *src, int linear, Sides ph, int keep_r, int skip1) {
   static const bool norun = getenv("MGX_C2F_OLD") != nullptr;
   if (linear && !norun) {
     // runs of KC coarse levels per lane: long enough to amortise the three-level window, short enough to keep >= ~2 waves per SIMD
@@ -916,8 +913,8 @@ int mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const d
     static const bool nosk = getenv("MGX_C2F_NOSKIP") != nullptr;
     if (keep_r) hipLaunchKernelGGL((k_coarse2fine_run<true, false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
     else if (skip1 && !nosk && !(F->nx & 1) && !(F->ny & 1)) hipLaunchKernelGGL((k_coarse2fine_run<false, true>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
-    else { hipLaunchKernelGGL((k_coarse2fine_run<false, false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC); return 1; }
-    return 0;
+    else hipLaunchKernelGGL((k_coarse2fine_run<false, false>), grd, blk, 0, st, *F, *C, src, ph, nt, KC);
+    return;
   }
   const int by = C->nz >= 4 ? 4 : C->nz;
   dim3 blk(WAVE, by), grd((C->ny + WAVE - 1) / WAVE, (C->nz + by - 1) / by, C->nx);
@@ -925,7 +922,6 @@ int mgxk_coarse2fine(hipStream_t st, const LevView *F, const LevView *C, const d
   if (linear) { if (keep_r) C2F(true, true); else C2F(true, false); }
   else { if (keep_r) C2F(false, true); else C2F(false, false); }
 #undef C2F
-  return 0;
 }
 void mgxk_divc_selftest(hipStream_t st, const double *a, const double *b, int n, unsigned long long *bad) {
   hipLaunchKernelGGL(k_divc_selftest, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, bad);

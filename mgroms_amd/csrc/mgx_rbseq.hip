@@ -690,24 +690,6 @@ int mgxk_rbseq_walk_apply(hipStream_t st, const LevView *L, int rb, Sides ph, in
   return mgx_launched();
 }
 
-// MGX_CHECK_P1 (debugging aid): how many entries of the k = 1 snapshot differ from p(k = 1) -- whole rows, halo columns and halo planes included
-__global__ void k_rbseq_check_snap(LevView L, int *bad) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-  if (t >= L.RS) return;
-  const double a = L.p1[(long long)i * L.RS + t], b = L.p[(long long)i * L.plane + t];
-  if (!(a == b)) atomicAdd(bad, 1);
-}
-int mgxk_rbseq_check_snap(hipStream_t st, const LevView *L) {
-  int *d = nullptr, h = -1;
-  if (hipMalloc((void **)&d, sizeof(int)) != hipSuccess) return -1;
-  (void)hipMemsetAsync(d, 0, sizeof(int), st);
-  hipLaunchKernelGGL(k_rbseq_check_snap, dim3((unsigned)((L->RS + 255) / 256), L->nx + 2), dim3(256), 0, st, *L, d);
-  (void)hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(d);
-  return h;
-}
-
 int mgxk_set_rbseq_timeout(double ms) {
   const long long ticks = (long long)(ms * 1e5);
   return hipMemcpyToSymbol(HIP_SYMBOL(g_rbs_timeout_ticks), &ticks, sizeof ticks) == hipSuccess ? 0 : 1;

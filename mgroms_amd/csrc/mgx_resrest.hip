@@ -175,9 +175,7 @@ __global__ __launch_bounds__(256, 1) void k_residual_restrict(LevView F, LevView
         dst[oc + rc] = z;                                                                                                   \
         mirror_store(C, dst, rc, j2, i2, jpos(C, j2), z, ph);                                                               \
         if (dup) { dup[oc + rc] = z; mirror_store(C, dup, rc, j2, i2, jpos(C, j2), z, ph); }                                 \
-        if (zero) { zero[oc + rc] = 0.0; mirror_store(C, zero, rc, j2, i2, jpos(C, j2), 0.0, ph);                           \
-          /* C.d0w set (sequential-order red-black): `zero` is the coarse p, whose k = 1 snapshot is then zero too -- no snapshot launch in front of the coarse relax */ \
-          if (C.d0w != nullptr && rc == 0) { LevView C2_ = C; C2_.plane = C.RS; C.d0w[(long long)i2 * C.RS + jpos(C, j2)] = 0.0; mirror_store(C2_, C.d0w, 0, j2, i2, jpos(C, j2), 0.0, ph); } } \
+        if (zero) { zero[oc + rc] = 0.0; mirror_store(C, zero, rc, j2, i2, jpos(C, j2), 0.0, ph); }                          \
       }                                                                                                                     \
     }
   /* interior rows, mg_relax.f90:484-496; diagonal = minus the sum of the fourteen couplings (mg_define_matrix.f90:632-639) */
