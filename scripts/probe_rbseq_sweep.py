@@ -22,6 +22,6 @@ if os.environ.get("MGX_TRACE"):
     nhydro.time_relax(1, 1)
     lib.mgx_debug_rbs(1, buf)
     t = list(buf); t0 = t[0]
-    names = ["walk_start", "lastw_stores_issued", "last_forward", "lastw_gate1", "lastw_flag", "lastw_u", "lastw_batch0_issued", "workers_end_max"]
-    print({n: (round((v - t0) / 100.0, 2) if v else None) for n, v in zip(names, t)}, "us (last colour pass of the sweep)")
+    names = ["walk_start", "last_worker_stores_issued", "last_forward", "last_worker_rows_requested", "last_worker_word_seen", "last_worker_u_read", None, None]
+    print({n: (round((v - t0) / 100.0, 2) if v else None) for n, v in zip(names, t) if n}, "us (last colour pass of the sweep)")
 mg.nhydro_clean()
