@@ -189,6 +189,39 @@ def test_config2_rb_256x256x32(mg, golden):
     assert np.all(np.abs(ho[1:4] - np.array(ref["first5"][:3])) <= 6e-4)
 
 
+def test_rb_sequential_order_512x512x64_against_the_exact_order(mg):
+    """BASELINE config 3's size (the bench's workload) with the reference DEFAULT ordering, relax_method='RB', cmatrix='real': two solve_p
+    iterations in the sequential order at speed (rb_seq -- at this size the level-1 correction runs inside the walk's launch across the XCDs,
+    levels 3-4 walk per workgroup, the coarsest level walks in registers) against the same two iterations in the bit-exact order (rb_exact, one
+    launch per plane: the mode the smaller tests pin on the oracle, which would need minutes here): p within 1e-12 of max|p|, residuals within
+    1e-13 + 1e-10 * ref -- north_star's bound -- and the fused launches really ran (fewer launches than with rbseq_fuse = 0, same bits)."""
+    nx, ny, nz = 512, 512, 64
+    mg.nhydro.set_option("rb_exact", 1)
+    try:
+        _gpu(mg, nx, ny, nz, relax_method="RB")
+        ne, he = mg.solve_p(1e-30, 2)
+        pe = mg.grid(1).p.copy()
+    finally:
+        mg.nhydro.set_option("rb_exact", 0)
+    got = {}
+    for fuse in (1, 0):
+        mg.nhydro.set_option("rbseq_fuse", fuse)
+        try:
+            _gpu(mg, nx, ny, nz, relax_method="RB")
+            n0 = mg.nhydro.counters()["launches"]
+            n, h = mg.solve_p(1e-30, 2)
+            got[fuse] = (mg.grid(1).p.copy(), h.copy(), mg.nhydro.counters()["launches"] - n0)
+            assert mg.nhydro.get_option("rbseq_fuse") == fuse    # (a lost hand-off would have switched it off -- and failed the call)
+        finally:
+            mg.nhydro.set_option("rbseq_fuse", 1)
+    p, h, launches = got[1]
+    assert n == ne == 2
+    assert np.abs(p - pe).max() <= 1e-12 * np.abs(pe).max(), np.abs(p - pe).max() / np.abs(pe).max()
+    assert np.all(np.abs(h[1:] - he[1:]) <= 1e-13 + 1e-10 * he[1:]), (h, he)
+    assert np.array_equal(p, got[0][0]) and np.array_equal(h, got[0][1])
+    assert launches < got[0][2], (launches, got[0][2])
+
+
 def test_config2_fc_256x256x32_bitwise(mg):
     _gpu(mg, 256, 256, 32, relax_method="FC")
     n, hist = mg.solve_p(1e-12, 3)
