@@ -3,7 +3,7 @@
 acquire; MI355X_MICROARCH.md asks for every word to be checked under uneven load): N repetitions of three solve_p iterations at
 512x512x64 with the correction inside the walk's launch, each compared bit for bit with the separate-launch result, while a second
 stream of the same process keeps the memory system busy with large device-to-device copies of varying size.
-python3 scripts/rbseq_fuse_soak.py [reps] [--json path]"""
+python3 scripts/rbseq_fuse_soak.py [reps [nx ny nz]] [--json path]"""
 import json
 import os
 import sys
@@ -21,13 +21,14 @@ from mgroms_amd.testcases import seamount_geometry, resting_column_state  # noqa
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 reps = int(args[0]) if args else 60
 jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-nx, ny, nz = 512, 512, 64
+nx, ny, nz = (int(a) for a in args[1:4]) if len(args) >= 4 else (512, 512, 64)   # e.g. 512 256 8: two workers per plane, workgroups on chunk boundaries
 torch.cuda.set_device(0)
 nhydro.set_verbose(0)
 
 
 def run(fuse):
     nhydro.set_option("rbseq_fuse", fuse)
+    nhydro.set_option("rbseq_fuse_min", 0)
     mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
     mg.nhydro_matrices(*seamount_geometry(nx, ny, 1, 1, 0), None, 4e3, 0.0, 0.0)
     nhydro.compute_rhs(*resting_column_state(nx, ny, nz))
@@ -58,6 +59,7 @@ for rep in range(reps):
     side.synchronize()
 still_fused = nhydro.get_option("rbseq_fuse")
 mg.nhydro_clean()
+nhydro.set_option("rbseq_fuse_min", 4 << 20)
 out = {"size": [nx, ny, nz], "repetitions": reps, "fused_launches_per_repetition": "3 F-cycle iterations: 30 level-1 colour passes", "different": bad,
        "rbseq_fuse_still_on": still_fused, "seconds": round(time.time() - t0, 1)}
 print(json.dumps(out))
