@@ -172,11 +172,13 @@ int mgx_set_verbose(int level);
  * "restrict_chain" (default 1; MGX_NO_RESTRICT_CHAIN): Fcycle's first-leg restrictions below level 1 on closed levels as one launch
  *   (mgx_kernels.hip: k_restrict_chain), 0 = one launch per level; the same bits.
  * "rbseq_fuse" (default 1; MGX_NO_RBSEQ_FUSE): with "rb_seq", walk and per-column correction of a colour in ONE launch -- on large levels
- *   (from "rbseq_fuse_min" cells of a colour on, default 4 Mi) the correction chases the walk across the XCDs (mgx_rbseq.hip: k_rbseq_scan,
- *   FUSE), on small levels (half-rows of at most 64 columns, at most 128 planes) every workgroup redoes the walk for its own planes
- *   (k_rbseq_walk_apply); 0 = the correction in a launch of its own behind the walk; the same bits.  The waits inside the large-level launch
- *   are bounded ("rbseq_timeout_ms", default 2000); a lost hand-off makes the next synchronising call fail and switches the option off
- *   (read it back).  "rbseq_d0_in_pass" (default 1): the colour pass also writes the walk's d0 (0 = a launch of its own; the same bits).
+ *   the correction chases the walk across the XCDs (mgx_rbseq.hip: k_rbseq_scan, FUSE), on small levels (half-rows of at most 64 columns,
+ *   at most 128 planes) every workgroup redoes the walk for its own planes (k_rbseq_walk_apply); 0 = the correction in a launch of its
+ *   own behind the walk; the same bits.  A lost hand-off inside the large-level launch (its waits are bounded) makes the next
+ *   synchronising call fail and switches the option off (read it back).
+ * "rbseq_fuse_min" (default 4194304): cells of a colour (nx * ny/2 * nz) from which on a level counts as large for "rbseq_fuse".
+ * "rbseq_timeout_ms" (default 2000; write-only): bound of the waits inside that launch.
+ * "rbseq_d0_in_pass" (default 1): the colour pass also writes the walk's d0 (0 = a launch of its own; the same bits).
  * "overlap" (default 0; MGX_OVERLAP=1): four colours on a level with neighbours, halos by the pushes: the boundary part of a colour pass and
  *   the exchange on a second stream beside the interior part.  Same bits; slower where it could be measured.
  * "ksp" (default 1): the persistent relax of the closed mid levels; read back 0 after it timed out (then off until mgx_init or "ksp" = 1).

@@ -27,6 +27,22 @@ def test_every_declared_symbol_is_exported(built):
         assert hasattr(L, s), s
 
 
+def test_documented_options_exist(built):
+    """Every run-time option include/mgx.h documents ("name" (default ...)) is known to the library: mgx_get_option succeeds (no GPU
+    needed -- options are plain state), with the documented default for the round-4 red-black switches."""
+    import ctypes
+    from mgroms_amd._lib import lib
+    hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    names = set(re.findall(r'"([a-z_0-9]+)" \(default', hdr))
+    assert {"rb_seq", "rb_exact", "rbseq_fuse", "rbseq_fuse_min", "rbseq_d0_in_pass", "fuse_closing", "restrict_chain", "overlap", "async"} <= names, names
+    L = lib()
+    v = ctypes.c_int(-12345)
+    for n in sorted(names - {"rbseq_timeout_ms", "ksp_timeout_ms", "p2p_timeout_ms"}):   # (device constants: write-only)
+        assert L.mgx_get_option(n.encode(), ctypes.byref(v)) == 0, n
+    for n, d in (("rb_seq", 1), ("rb_exact", 0), ("rbseq_fuse", 1), ("rbseq_fuse_min", 4 << 20), ("rbseq_d0_in_pass", 1)):
+        assert L.mgx_get_option(n.encode(), ctypes.byref(v)) == 0 and v.value == d, (n, v.value)
+
+
 @pytest.mark.parametrize("cfg", [(64, 64, 16, 1, 1, 8), (32, 32, 16, 2, 2, 8), (512, 512, 64, 1, 1, 8), (64, 32, 32, 4, 2, 8),
                                  (512, 512, 64, 2, 2, 8), (512, 1024, 128, 4, 2, 16), (128, 128, 64, 4, 2, 64), (16, 16, 8, 2, 1, 8),
                                  (16, 16, 8, 1, 2, 8), (32, 64, 8, 4, 4, 16)])
