@@ -104,6 +104,9 @@ int mgx_compute_rhs(const double *u, const double *v, const double *w, const dou
 /* grid(lev)%<field> accessors (mg_grids.f90:24-65), host layout as described above */
 int mgx_nlevs(void);
 int mgx_level_dims(int lev, int *nx, int *ny, int *nz);
+/* sequential-order red-black, windowed walk (option "rbseq_window"): the level's contraction bound rho = max |ag5| + |ag8| (-1: not a red-black
+ * solver with cmatrix='real') and the planes of warm-up chosen from it (0 = the walk over the whole level stays).  No Fortran counterpart. */
+int mgx_rbseq_window_info(int lev, double *rho, int *planes);
 /* out[0..9] = npx,npy,incx,incy,gather,ngx,ngy,key,color,0 ; out[10..17] = neighbours S,E,N,W,SW,SE,NE,NW (-1 = none) */
 int mgx_level_info(int lev, int *out);
 /* Pure host logic of find_grid_levels / define_grid_dims / define_neighbours / define_gather_informations
@@ -176,6 +179,14 @@ int mgx_set_verbose(int level);
  *   at most 128 planes) every workgroup redoes the walk for its own planes (k_rbseq_walk_apply); 0 = the correction in a launch of its
  *   own behind the walk; the same bits.  A lost hand-off inside the large-level launch (its waits are bounded) makes the next
  *   synchronising call fail and switches the option off (read it back).
+ * "rbseq_window" (default 1; MGX_NO_RBSEQ_WINDOW): with "rb_seq", walk and correction of a colour in one launch WITHOUT a walk over the whole
+ *   level (mgx_rbseq.hip: k_rbseq_window).  The walk's recurrence contracts by rho = max |ag5| + |ag8| per plane (a property of the matrix, found
+ *   when the coefficients are built: mgx_rbseq_window_info); a walk started from zero m planes before a plane has forgotten its start to
+ *   rho^m, and m is chosen so that rho^m <= 2^-64 (half an ulp of the largest increment).  Every workgroup walks the m planes in front of
+ *   its own over its chunk of columns +- 32; nothing is handed from one workgroup to another.  Used on every level where m <= 48 (rho <~ 0.39:
+ *   0.03-0.04 on the seamount problem); otherwise, and with 0, the walk over the whole level ("rbseq_fuse").  Not the same bits as that
+ *   walk (a truncation of 2^-64 of the largest increment), inside the same tolerances (tests: 1e-12 per relax call against "rb_exact").
+ *   Read-only: "rbseq_window_colours" (colours done that way since mgx_init).
  * "rbseq_fuse_min" (default 4194304): cells of a colour (nx * ny/2 * nz) from which on a level counts as large for "rbseq_fuse".
  * "rbseq_timeout_ms" (default 2000; write-only): bound of the waits inside that launch.
  * "rbseq_d0_in_pass" (default 1): the colour pass also writes the walk's d0 (0 = a launch of its own; the same bits).

@@ -42,6 +42,9 @@ int mgxk_rbseq_walk_apply(hipStream_t, const LevView *, int, Sides, int);
 int mgxk_rbseq_scan_apply(hipStream_t, const LevView *, int, Sides, int, int, unsigned int *, unsigned int, int *, int, long long);
 int mgxk_set_rbseq_timeout(double);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
+void mgxk_rbseq_rho(hipStream_t, const LevView *, double *);
+int mgxk_rbseq_window_planes(double);
+int mgxk_rbseq_window(hipStream_t, const LevView *, int, Sides, int, int);
 int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
@@ -129,6 +132,7 @@ struct Level {
   unsigned long long p2p_gseq = 0;
   unsigned int *ksp_done = nullptr; unsigned int ksp_seq = 0;  // per-plane progress counters of the persistent mid-level relax (k_relax_ksp) and their common value
   unsigned int *rbs_flag = nullptr; unsigned int rbs_seq = 0;  // progress word of the sequential-order red-black walk and the number of its launches (mgx_rbseq.hip: k_rbseq_scan, FUSE)
+  double rbs_rho = -1.0; int rbs_m = 0;  // sequential-order red-black, windowed walk (k_rbseq_window): rho = max |ag5| + |ag8| of the level, found at set-up, and the planes of warm-up it asks for (0 = none: the walk over the whole level)
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
   double *f2d_store[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, *tab_store[2] = {nullptr, nullptr};  // m4,d4,m7,d7,h2,hi2,ze2 and cffw,csw (LevView)
@@ -197,6 +201,9 @@ struct State {
   int rbseq_fuse_min = 4 << 20;  // option "rbseq_fuse_min": cells of a colour (nx * ny/2 * nz) from which on the fused launch is used (below, the hand-off costs more than the correction's own launch: 256x256x32 0.111 ms per sweep fused, 0.099 separate)
   int rbseq_d0_in_pass = 1;  // option "rbseq_d0_in_pass" (A/B): 0 = k_rbseq_d0 as a launch of its own
   int rbseq_test_stall = 0;  // test hook: the walk of the fused launch never reports its progress (the bounded waits must end the launch)
+  int rbseq_window = 1;  // option "rbseq_window" / MGX_NO_RBSEQ_WINDOW=1: walk and correction of a colour by the windowed walk (k_rbseq_window: no hand-off, no walk over the whole level) on the levels whose contraction bound allows it (Level::rbs_m)
+  long long n_window = 0;  // colours done that way
+  double *rho_dev = nullptr, rho_host[32];  // the levels' rho (k_rbseq_rho) on the device and after the set-up's copy
   int rbseq_fuse = 1;    // option "rbseq_fuse" / MGX_NO_RBSEQ_FUSE=1: the correction of the sequential-order red-black inside the walk's launch (k_rbseq_scan, FUSE) instead of a launch behind it (A/B)
   int use_chain = 1;     // option "restrict_chain" / MGX_NO_RESTRICT_CHAIN=1: Fcycle's first-leg restrictions below level 1 as one launch (A/B)
   int fuse_closing = 1;  // option "fuse_closing" / MGX_NO_FUSE_CLOSING=1: the closing compute_residual(1) of a solve_p iteration also restricts its r for the next Fcycle, one kernel, no r written (A/B)
@@ -588,6 +595,12 @@ int relax(int lev, int nsweeps) {
           // y is in p; the walk over the planes, then p += g s with the mirrors (mgx_rbseq.hip).  A level wider than the walk takes
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
           // small levels whose pass left d0 in u1: walk and correction in one launch, every workgroup walking for itself (k_rbseq_walk_apply)
+          // the windowed walk where the level's contraction bound allows it (k_rbseq_window): one launch, no hand-off, no walk over the level
+          if (have_d0 && S.rbseq_window && L.rbs_m > 0 && mgxk_rbseq_window(S.stream, &L.v, rb, ph, closed ? 1 : 0, L.rbs_m)) {
+            S.n_launch++; S.n_window++; fused = 1;
+            CHK(fill_halo_js(L, L.v.p, fused));
+            continue;
+          }
           if (have_d0 && S.rbseq_fuse && mgxk_rbseq_walk_apply(S.stream, &L.v, rb, ph, closed ? 1 : 0)) {
             S.n_launch++; fused = 1;
             CHK(fill_halo_js(L, L.v.p, fused));
@@ -919,7 +932,19 @@ int gather2d(Level &L, double *src_tmp, double *dst) {
   return 0;
 }
 
+// the planes of warm-up each level's windowed red-black walk needs (mgx_rbseq.hip: k_rbseq_window), from the rho the set-up has just copied back
+static void set_window_planes() {
+  for (int l = 0; l < S.nlevs && l < 32; l++) {
+    Level &L = S.lev[l];
+    if (!L.v.gk || !S.rho_dev) { L.rbs_rho = -1.0; L.rbs_m = 0; continue; }
+    L.rbs_rho = S.rho_host[l];
+    L.rbs_m = mgxk_rbseq_window_planes(L.rbs_rho);
+    if (S.verbose > 1 && S.rank == 0) printf(" level %d: red-black walk contracts by %.4g per plane: %d planes of warm-up%s\n", l + 1, L.rbs_rho, L.rbs_m, L.rbs_m ? "" : " (none: the walk over the whole level stays)");
+  }
+}
+
 int define_matrices() {
+  if (S.rho_dev) HIPCHK(hipMemsetAsync(S.rho_dev, 0, sizeof S.rho_host, S.stream));
   for (int l = 0; l < S.nlevs; l++) {
     Level &L = S.lev[l];
     if (l > 0) {
@@ -972,6 +997,7 @@ int define_matrices() {
     else for (int s = 0; s < 8; s++) { mgxk_convert(S.stream, &L.v, L.v.cA[s], L.g.cA + (size_t)s * L.nz * (L.ny + 2) * (L.nx + 2), 1, 0, 0); S.n_launch++; }
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     if (L.v.gk) { mgxk_rbseq_setup(S.stream, &L.v); S.n_launch++; }
+    if (L.v.gk && S.rho_dev && l < 32) { mgxk_rbseq_rho(S.stream, &L.v, S.rho_dev + l); S.n_launch++; }
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     if (L.nz <= 1024) { mgxk_convert2(S.stream, &L.v, L.zy_store, L.zx_store, L.g.szy); S.n_launch++; }
     else { mgxk_convert(S.stream, &L.v, L.zy_store, L.g.szy, 1, 0, 0); mgxk_convert(S.stream, &L.v, L.zx_store, L.g.szx, 1, 0, 0); S.n_launch += 2; }
@@ -981,7 +1007,9 @@ int define_matrices() {
     mgxs_zw_js(S.stream, &L.g, &L.v, S.hlim, S.theta_b, S.theta_s); S.n_launch += 3;
     if (S.no_mf || S.par.bmask) { L.v.zy = L.v.zx = nullptr; L.v.m4 = nullptr; }  // masked coefficients are not rebuilt from the slopes
   }
+  if (S.rho_dev) HIPCHK(hipMemcpyAsync(S.rho_host, S.rho_dev, sizeof S.rho_host, hipMemcpyDeviceToHost, S.stream));
   CHK(sync_stream());
+  set_window_planes();
   S.have_matrix = true;
   return 0;
 }
@@ -1377,7 +1405,7 @@ void mgx_clean(void) {
   if (S.ev_s) (void)hipEventDestroy(S.ev_s);
   if (S.ev_x) (void)hipEventDestroy(S.ev_x);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, rf = S.rbseq_fuse, rfm = S.rbseq_fuse_min, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, rf = S.rbseq_fuse, rw = S.rbseq_window, rfm = S.rbseq_fuse_min, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
   std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
@@ -1386,7 +1414,7 @@ void mgx_clean(void) {
   S = State();
   S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.rbseq_fuse = rf; S.rbseq_fuse_min = rfm; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.rbseq_fuse = rf; S.rbseq_window = rw; S.rbseq_fuse_min = rfm; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1482,6 +1510,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   S.npartial = (int)max_part;
   CHK(dmalloc(&S.d_partial, max_part));
   CHK(dmalloc(&S.d_scalar, 8));
+  if (S.method == M_RB && S.real) CHK(dmalloc(&S.rho_dev, 32));
   HIPCHK(hipHostMalloc((void **)&S.h_scalar, 8 * sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&S.kerr, 64, hipHostMallocMapped));
   *S.kerr = 0;
@@ -1516,6 +1545,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (getenv("MGX_NO_FUSE_CLOSING")) S.fuse_closing = 0;
   if (getenv("MGX_NO_RESTRICT_CHAIN")) S.use_chain = 0;
   if (getenv("MGX_NO_RBSEQ_FUSE")) S.rbseq_fuse = 0;
+  if (getenv("MGX_NO_RBSEQ_WINDOW")) S.rbseq_window = 0;
   if (getenv("MGX_OVERLAP")) S.overlap = atoi(getenv("MGX_OVERLAP"));
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
@@ -1696,6 +1726,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "fuse_closing")) S.fuse_closing = value;
   else if (streq(name, "restrict_chain")) S.use_chain = value;
   else if (streq(name, "rbseq_fuse")) S.rbseq_fuse = value;
+  else if (streq(name, "rbseq_window")) S.rbseq_window = value;
   else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
@@ -1742,6 +1773,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "fuse_closing")) *value = S.fuse_closing;
   else if (streq(name, "restrict_chain")) *value = S.use_chain;
   else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
+  else if (streq(name, "rbseq_window")) *value = S.rbseq_window;
+  else if (streq(name, "rbseq_window_colours")) *value = (int)S.n_window;
   else if (streq(name, "rbseq_fuse_min")) *value = S.rbseq_fuse_min;
   else if (streq(name, "rbseq_d0_in_pass")) *value = S.rbseq_d0_in_pass;
   else if (streq(name, "overlap")) *value = S.overlap;
@@ -1804,6 +1837,7 @@ int mgx_toc(int lev, const char *name) {
 int mgx_synchronize(void) { NEED_INIT(); return sync_stream(); }
 int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }
 int mgx_level_dims(int lev, int *nx, int *ny, int *nz) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *nx = L.nx; *ny = L.ny; *nz = L.nz; return 0; }
+int mgx_rbseq_window_info(int lev, double *rho, int *planes) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *rho = L.rbs_rho; *planes = L.rbs_m; return 0; }
 int mgx_level_info(int lev, int *out) {
   NEED_LEV(lev);
   const Level &L = S.lev[lev - 1];
@@ -1862,6 +1896,13 @@ int mgx_set_field(int lev, int field, const double *host) {
     for (int s = 0; s < 8; s++) mgxk_convert(S.stream, &L.v, L.v.cA[s], S.ref_scratch, 8, s, 0);
     mgxs_pivots(S.stream, &L.v);
     if (L.v.gk) mgxk_rbseq_setup(S.stream, &L.v);
+    if (L.v.gk && S.rho_dev && lev <= 32) {
+      HIPCHK(hipMemsetAsync(S.rho_dev + lev - 1, 0, sizeof(double), S.stream));
+      mgxk_rbseq_rho(S.stream, &L.v, S.rho_dev + lev - 1);
+      HIPCHK(hipMemcpyAsync(S.rho_host, S.rho_dev, sizeof S.rho_host, hipMemcpyDeviceToHost, S.stream));
+      CHK(sync_stream());
+      set_window_planes();
+    }
     L.v.zy = L.v.zx = nullptr;  // a user-supplied matrix is used as stored
     L.v.m4 = nullptr;
     S.have_matrix = true;

@@ -528,6 +528,136 @@ __global__ __launch_bounds__(256) void k_rbseq_walk_apply(LevView L, int rb, Sid
   }
 }
 
+// (b) + (c) in one launch with NO hand-off and no sequential walk over the level: the WINDOWED walk (option "rbseq_window").
+// The recurrence of (b), u(.,i) = d0(.,i) + M_i u(.,i-1), contracts: every row of M_i holds the two multipliers ag5, ag8 of one column, so
+// ||M_i||_inf <= rho = max over the level of |ag5| + |ag8| (k_rbseq_rho, found at set-up: a property of the matrix; 0.03-0.04 on every level
+// of the seamount problem).  A walk started from zero m planes before plane i therefore gives u(.,i) to within rho^m * max|u|, and m is
+// chosen at set-up so that rho^m <= 2^-64: below half an ulp of max|u|, the same order as the reassociation (a) + (c) make anyway.  The
+// dependence cone of a 64-column chunk widens by one column every two planes, so a workgroup walks a window of its chunk +- 32 columns
+// (one wave, two columns per lane; the whole half-row where that is at most 64 columns) over the m planes in front of its own, with u in
+// registers and the last plane's in LDS -- operands that the colour pass and the set-up left in the L2 / Infinity Cache, ~25 KB per
+// workgroup -- while its four other waves have the rows of y and g of the workgroup's plane in flight; then p = y + g s as in
+// k_rbseq_apply.  Nothing is handed from one workgroup to another: no progress words, no forwarding waves, no placement assumption.
+// Where rho is too close to one (m > RBW_MAXM) the walk over the whole level stays (k_rbseq_scan).
+// Workgroup = chunk ch of plane i, rows [kz*4*KR, (kz+1)*4*KR): waves 0-3 hold KR rows each (KR = 16 at nz = 64 ... 1 at nz = 4), wave 4 walks.
+constexpr int RBW_MAXM = 48, RBW_D = 8;
+template <int CPL, int KR, bool SNAPW>
+__global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz) {
+  __shared__ double ul[64 * CPL + 2];   // u of plane i-1 over the window at 1 + (column - w0); a zero on either side
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1;
+  // block -> (chunk, plane, row group).  XCD-aware where the planes divide by 8 (xmap): workgroup b runs on XCD b % 8, which takes a contiguous
+  // eighth of the planes -- the windows of consecutive planes overlap in all but one plane, so the walks' operands are fetched into ONE L2
+  // (with the plain order every XCD reads every plane's: +12 % of the launch's traffic on level 1 of 512x512x64)
+  int ch, i, kz;
+  if (xmap) {
+    const int b = blockIdx.x, x = b & 7, r = b >> 3, per = nch * nkz;
+    i = 1 + x * (L.nx >> 3) + r / per; ch = r % nch; kz = (r / nch) % nkz;
+  } else { ch = blockIdx.x; i = 1 + blockIdx.y; kz = blockIdx.z; }
+  const int w0 = CPL == 1 ? 0 : ch * 64 - 32;
+  const long long RS = L.RS;
+  const int jh = ch * 64 + lane;
+  const bool live = jh < nyh;
+  const int jodd = rb_jodd(i, rb);
+  const int jhc = live ? jh : nyh - 1;
+  const int c = jodd ? L.HO + jhc : L.EO + jhc + 1;
+  const int j = jodd ? 2 * jhc + 1 : 2 * jhc + 2;
+  const long long o = (long long)i * L.plane;
+  double *__restrict__ p = L.p;
+  const int k0 = (kz * 4 + (wv & 3)) * KR;
+  double pv[KR], gv[KR], c5 = 0.0, c8 = 0.0;
+  if (wv == 4) {
+    double up[CPL];
+    bool ok[CPL];
+    int jc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+      const int jw = w0 + lane * CPL + q;
+      up[q] = 0.0; ok[q] = jw >= 0 && jw < nyh; jc[q] = jw < 0 ? 0 : (jw < nyh ? jw : nyh - 1);
+    }
+    const int ia = i - m > 1 ? i - m : 1;   // planes ia .. i-1 (plane 0 is halo: u = 0)
+    if (ia < i) {
+      const double *__restrict__ d0 = L.u1, *__restrict__ g58 = L.ag58;
+      double rd[RBW_D][CPL], ra[RBW_D][CPL], rbb[RBW_D][CPL];
+      // every request is unconditional (planes past i-1 clamp to i-1, columns outside the half-row to its ends): the waits stay counted
+#define WLOADW(ip, slot)                                                                                         \
+      {                                                                                                          \
+        const int i_ = (ip) < i ? (ip) : i - 1;                                                                  \
+        const long long q_ = (long long)i_ * RS + (rb_jodd(i_, rb) ? L.HO : L.EO + 1);                           \
+        _Pragma("unroll") for (int q = 0; q < CPL; q++) {                                                        \
+          rd[slot][q] = d0[q_ + jc[q]]; LD_PAIR(g58 + 2 * (q_ + jc[q]), ra[slot][q], rbb[slot][q])               \
+        }                                                                                                        \
+      }
+#pragma unroll
+      for (int d = 0; d < RBW_D; d++) { WLOADW(ia + d, d) asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+      for (int i0 = ia; i0 < i; i0 += RBW_D) {
+#pragma unroll
+        for (int d = 0; d < RBW_D; d++) {
+          const int ip = i0 + d;
+          if (ip < i) {
+            const bool jo = rb_jodd(ip, rb);
+            // odd j (position HO + jh):  j+1 <-> previous plane's jh,     j-1 <-> its jh - 1
+            // even j (EO + 1 + jh):      j+1 <-> previous plane's jh + 1, j-1 <-> its jh
+            const double e_r = wave_shr1(up[CPL - 1]), e_l = wave_shl1(up[0]);
+            double un[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+              const double lo = q > 0 ? up[q > 0 ? q - 1 : 0] : e_r, hi = q < CPL - 1 ? up[q < CPL - 1 ? q + 1 : 0] : e_l;
+              const double ua = jo ? up[q] : hi, ub = jo ? lo : up[q];   // u(j+1,i-1), u(j-1,i-1)
+              double t = __builtin_fma(-ra[d][q], ua, rd[d][q]);
+              t = __builtin_fma(-rbb[d][q], ub, t);
+              un[q] = ok[q] ? t : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; q++) up[q] = un[q];
+          }
+          WLOADW(ip + RBW_D, d)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#undef WLOADW
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; q++) ul[1 + lane * CPL + q] = up[q];
+    if (lane == 0) { ul[0] = 0.0; ul[64 * CPL + 1] = 0.0; }
+  } else {
+    const double *__restrict__ g = L.gk;
+    c5 = L.cA[4][o + c]; c8 = L.cA[7][o + c];
+#pragma unroll
+    for (int t = 0; t < KR; t++) { const long long ko = o + (long long)(k0 + t) * RS + c; pv[t] = p[ko]; gv[t] = ld_rt(g + ko, nt); }
+  }
+  __syncthreads();
+  if (wv == 4 || !live) return;
+  const int wi = 1 + jh - w0;   // the column's own place in ul
+  const double ujp = jodd ? ul[wi] : ul[wi + 1], ujm = jodd ? ul[wi - 1] : ul[wi];
+  const double s = 0.0 - c5 * ujp - c8 * ujm;
+#pragma unroll
+  for (int t = 0; t < KR; t++) {
+    const int k = k0 + t;
+    const long long ro = (long long)k * RS;
+    const double v = pv[t] + gv[t] * s;
+    p[o + ro + c] = v;
+    mirror_store(L, p, ro, j, i, c, v, ph);
+    if (SNAPW && k == 0) {
+      LevView L2 = L; L2.plane = L.RS;  // the snapshot: one row per plane
+      L.p1[(long long)i * L.RS + c] = v;
+      mirror_store(L2, L.p1, 0, j, i, c, v, ph);
+    }
+  }
+}
+
+// rho = max over the interior columns of |ag5| + |ag8| (a bound of the walk's step in the maximum norm); non-negative doubles order like their bit patterns
+__global__ void k_rbseq_rho(LevView L, unsigned long long *out) {
+  const int jj = 1 + blockIdx.x * blockDim.x + threadIdx.x, i = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+  double v = 0.0;
+  if (jj <= L.ny && i <= L.nx) {
+    const long long q = (long long)i * L.RS + jpos(L, jj);
+    v = __builtin_fabs(L.ag58[2 * q]) + __builtin_fabs(L.ag58[2 * q + 1]);
+  }
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  for (int s = 32; s >= 1; s >>= 1) { const unsigned long long ob = __shfl_xor(b, s); b = ob > b ? ob : b; }
+  if (threadIdx.x == 0) atomicMax(out, b);
+}
+
 template <int CPL, int D, int NW, bool D0IN>
 static bool rbseq_fused_launch(hipStream_t st, const LevView *L, int nhelp, int rb, const RbFuse &F, int snapw) {
   if constexpr (NW == 1 && D % RBF_CH == 0) {
@@ -687,6 +817,39 @@ int mgxk_rbseq_walk_apply(hipStream_t st, const LevView *L, int rb, Sides ph, in
                else hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 0, true>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt); }
   else { if (rb & 1) hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 1, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt);
          else hipLaunchKernelGGL((k_rbseq_walk_apply<DW, 0, false>), dim3(nblk), dim3(256), lds, st, *L, rb, ph, pb, nt); }
+  return mgx_launched();
+}
+
+// rho of the level into *out (device memory, zero before the first call; mgx_api.cpp reads it back with the set-up's own synchronisation)
+void mgxk_rbseq_rho(hipStream_t st, const LevView *L, double *out) {
+  hipLaunchKernelGGL(k_rbseq_rho, dim3((L->ny + 63) / 64, (L->nx + 3) / 4), dim3(64, 4), 0, st, *L, (unsigned long long *)out);
+}
+// planes of warm-up after which a walk started from zero has forgotten its start to 2^-64: rho^m <= 2^-64; 0 = too many (or rho not a number)
+int mgxk_rbseq_window_planes(double rho) {
+  if (!(rho >= 0.0) || rho >= 1.0) return 0;
+  if (rho < 1e-300) return 1;
+  const double m = __builtin_ceil(64.0 * 0.6931471805599453 / -__builtin_log(rho));
+  return m < 2.0 ? 2 : (m > (double)RBW_MAXM ? 0 : (int)m);
+}
+// (b) + (c) by the windowed walk (k_rbseq_window); needs d0 in u1 (the colour pass or k_rbseq_d0 wrote it) and m from mgxk_rbseq_window_planes.
+// Returns 1 when launched.
+int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, int m) {
+  const int nyh = L->ny / 2, nz = L->nz;
+  if (L->gk == nullptr || m < 1 || m > RBW_MAXM || nyh < 1 || (L->ny & 1) || L->nx > 65535) return 0;
+  const int kr = nz % 64 == 0 ? 16 : (nz % 32 == 0 ? 8 : (nz % 16 == 0 ? 4 : (nz % 8 == 0 ? 2 : (nz % 4 == 0 ? 1 : 0))));
+  if (!kr || nz / (4 * kr) > 65535) return 0;
+  mgx_before_launch();
+  static const bool no_xmap = getenv("MGX_RBSEQ_WINDOW_NO_XMAP") != nullptr;   // A/B
+  const int nt = level_streams(L), cpl = nyh <= WAVE ? 1 : 2, nch = (nyh + WAVE - 1) / WAVE, nkz = nz / (4 * kr);
+  const int xmap = !no_xmap && L->nx % 8 == 0 && (long long)nch * L->nx * nkz < (1LL << 31);
+  const dim3 grd = xmap ? dim3(nch * L->nx * nkz) : dim3(nch, L->nx, nkz), blk(320);
+#define WIN_CASE(CPLV, KRV)                                                                                          \
+  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz); \
+    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz); }
+#define WIN_KR(CPLV) { if (kr == 16) WIN_CASE(CPLV, 16) else if (kr == 8) WIN_CASE(CPLV, 8) else if (kr == 4) WIN_CASE(CPLV, 4) else if (kr == 2) WIN_CASE(CPLV, 2) else WIN_CASE(CPLV, 1) }
+  if (cpl == 1) WIN_KR(1) else WIN_KR(2)
+#undef WIN_KR
+#undef WIN_CASE
   return mgx_launched();
 }
 

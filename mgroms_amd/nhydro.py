@@ -208,6 +208,14 @@ def nlevs():
     return lib().mgx_nlevs()
 
 
+def rbseq_window_info(lev):
+    """(rho, planes): the contraction bound of the level's red-black walk and the planes of warm-up of the windowed walk
+    (option "rbseq_window", include/mgx.h); planes = 0: the walk over the whole level stays."""
+    rho, m = C.c_double(), C.c_int()
+    check(lib().mgx_rbseq_window_info(lev, C.byref(rho), C.byref(m)))
+    return rho.value, m.value
+
+
 class _Level:
     """grid(lev) (mg_grids.f90:24-65): dims, decomposition info and host copies of the level's arrays."""
 

@@ -24,12 +24,16 @@ torch.cuda.set_device(0)
 nhydro.set_verbose(0)
 out = {"size": [nx, ny, nz], "modes": {}}
 fields = {}
-for mode, opts in (("exact", {"rb_exact": 1, "rb_seq": 0}), ("parallel", {"rb_exact": 0, "rb_seq": 0}), ("sequential", {"rb_exact": 0, "rb_seq": 1})):
+for mode, opts in (("exact", {"rb_exact": 1, "rb_seq": 0}), ("parallel", {"rb_exact": 0, "rb_seq": 0}),
+                   ("sequential_walk", {"rb_exact": 0, "rb_seq": 1, "rbseq_window": 0}),      # the walk over the whole level (round 4's first form)
+                   ("sequential", {"rb_exact": 0, "rb_seq": 1, "rbseq_window": 1})):          # the windowed walk (default)
     for k, v in opts.items():
         nhydro.set_option(k, v)
     mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="RB"))
     mg.nhydro_matrices(*seamount_geometry(nx, ny, 1, 1, 0), None, 4e3, 0.0, 0.0)
     nhydro.compute_rhs(*resting_column_state(nx, ny, nz))
+    if mode == "sequential":
+        out["window"] = {f"level{l}": dict(zip(("rho", "planes"), nhydro.rbseq_window_info(l))) for l in range(1, mg.nlevs() + 1)}
     n, hist = mg.solve_p(1e-30, 2)          # two iterations from p = 0: the iterate the modes are compared on
     fields[mode] = (mg.grid(1).p, hist.copy())
     reps = 2 if mode == "exact" else 20
@@ -45,10 +49,12 @@ for mode, opts in (("exact", {"rb_exact": 1, "rb_seq": 0}), ("parallel", {"rb_ex
     n, _ = mg.solve_p(1e-30, 1 if mode == "exact" else 10)
     torch.cuda.synchronize(); tf = (time.perf_counter() - t0) / n * 1e3
     out["modes"][mode] = {"level1_sweep_ms": round(sweep, 4), "vcycle_ms": round(tv, 4), "fcycle_iteration_ms": round(tf, 4)}
+    if mode.startswith("sequential"):
+        out["modes"][mode]["window_colours"] = nhydro.get_option("rbseq_window_colours")
     mg.nhydro_clean()
-nhydro.set_option("rb_exact", 0); nhydro.set_option("rb_seq", 1)
+nhydro.set_option("rb_exact", 0); nhydro.set_option("rb_seq", 1); nhydro.set_option("rbseq_window", 1)
 pe, he = fields["exact"]
-for mode in ("parallel", "sequential"):
+for mode in ("parallel", "sequential_walk", "sequential"):
     p, h = fields[mode]
     out["modes"][mode]["p_vs_exact_order"] = float(np.abs(p - pe).max() / np.abs(pe).max())
     out["modes"][mode]["residual_vs_exact_order"] = float(np.max(np.abs(h[1:] - he[1:]) / he[1:]))

@@ -51,6 +51,7 @@ def main():
     nhydro.set_option("rb_seq", 0 if par else 1)
     if fuse0:
         nhydro.set_option("rbseq_fuse_min", 0)
+        nhydro.set_option("rbseq_window", 0)   # (the windowed walk, the default, needs no hand-off: this case is about the launch that has one)
     nhydro.set_option("overlap", 1)   # the exchange beside the interior sweep (off by default: slower on a shared GPU); the bits must not depend on it
     mg.nhydro_init(nx, ny, nz, npx, npy, rank, par, comm=comm)
     stamp("init")

@@ -192,7 +192,7 @@ def test_config2_rb_256x256x32(mg, golden):
 def test_rb_sequential_order_512x512x64_against_the_exact_order(mg):
     """BASELINE config 3's size (the bench's workload) with the reference DEFAULT ordering, relax_method='RB', cmatrix='real': two solve_p
     iterations in the sequential order at speed (rb_seq -- at this size the level-1 correction runs inside the walk's launch across the XCDs,
-    levels 3-4 walk per workgroup, the coarsest level walks in registers) against the same two iterations in the bit-exact order (rb_exact, one
+    levels 3-4 walk per workgroup, the coarsest level walks in registers; and, the default since, the windowed walk on levels 1-4) against the same two iterations in the bit-exact order (rb_exact, one
     launch per plane: the mode the smaller tests pin on the oracle, which would need minutes here): p within 1e-12 of max|p|, residuals within
     1e-13 + 1e-10 * ref -- north_star's bound -- and the fused launches really ran (fewer launches than with rbseq_fuse = 0, same bits)."""
     nx, ny, nz = 512, 512, 64
@@ -204,22 +204,25 @@ def test_rb_sequential_order_512x512x64_against_the_exact_order(mg):
     finally:
         mg.nhydro.set_option("rb_exact", 0)
     got = {}
-    for fuse in (1, 0):
-        mg.nhydro.set_option("rbseq_fuse", fuse)
+    for mode, window, fuse in (("window", 1, 1), (1, 0, 1), (0, 0, 0)):   # the default (windowed walk), then the walk over the whole level: fused launch, separate launches
+        mg.nhydro.set_option("rbseq_fuse", fuse); mg.nhydro.set_option("rbseq_window", window)
         try:
             _gpu(mg, nx, ny, nz, relax_method="RB")
-            n0 = mg.nhydro.counters()["launches"]
+            n0 = mg.nhydro.counters()["launches"]; w0 = mg.nhydro.get_option("rbseq_window_colours")
             n, h = mg.solve_p(1e-30, 2)
-            got[fuse] = (mg.grid(1).p.copy(), h.copy(), mg.nhydro.counters()["launches"] - n0)
+            got[mode] = (mg.grid(1).p.copy(), h.copy(), mg.nhydro.counters()["launches"] - n0, mg.nhydro.get_option("rbseq_window_colours") - w0)
             assert mg.nhydro.get_option("rbseq_fuse") == fuse    # (a lost hand-off would have switched it off -- and failed the call)
         finally:
-            mg.nhydro.set_option("rbseq_fuse", 1)
-    p, h, launches = got[1]
+            mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_window", 1)
     assert n == ne == 2
-    assert np.abs(p - pe).max() <= 1e-12 * np.abs(pe).max(), np.abs(p - pe).max() / np.abs(pe).max()
-    assert np.all(np.abs(h[1:] - he[1:]) <= 1e-13 + 1e-10 * he[1:]), (h, he)
-    assert np.array_equal(p, got[0][0]) and np.array_equal(h, got[0][1])
-    assert launches < got[0][2], (launches, got[0][2])
+    for mode in ("window", 1):
+        p, h, launches, wcol = got[mode]
+        assert np.abs(p - pe).max() <= 1e-12 * np.abs(pe).max(), (mode, np.abs(p - pe).max() / np.abs(pe).max())
+        assert np.all(np.abs(h[1:] - he[1:]) <= 1e-13 + 1e-10 * he[1:]), (mode, h, he)
+    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[1][1], got[0][1])
+    assert got[1][2] < got[0][2], (got[1][2], got[0][2])
+    # the windowed walk served every colour of levels 1-4 (levels 5, 6 run the plane loop inside their one-workgroup kernels), no launch more than the fused walk
+    assert got["window"][3] > 0 and got[1][3] == 0 and got[0][3] == 0 and got["window"][2] <= got[1][2], [g[2:] for g in got.values()]
 
 
 def test_config2_fc_256x256x32_bitwise(mg):

@@ -253,6 +253,7 @@ def test_rb_sequential_order_correction_inside_the_walk_launch(mg, dims):
 
     try:
         mg.nhydro.set_option("rbseq_fuse_min", 0)
+        mg.nhydro.set_option("rbseq_window", 0)   # (the windowed walk would serve these levels: this test is about the walk over the whole level)
         ref, lref = run(0)
         fused_levels = 0
         for rep in range(6 if nx * ny * nz > 100000 else 24):
@@ -262,7 +263,7 @@ def test_rb_sequential_order_correction_inside_the_walk_launch(mg, dims):
             fused_levels = sum(1 for lev in ref if lgot[lev] == lref[lev] - 6)   # 3 sweeps x 2 colours, one launch fewer each
         assert fused_levels >= 1, (lref, lgot)
     finally:
-        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20)
+        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20); mg.nhydro.set_option("rbseq_window", 1)
     lev = 1
     o.field("p", lev)[...] = init[lev][0]; o.field("b", lev)[...] = init[lev][1]; o.fill_halo(lev, "p")
     o.relax(lev, 3)
@@ -285,6 +286,7 @@ def test_rb_sequential_order_fused_launch_bounded_waits(mg):
     o.field("p")[...] = p0; o.field("b")[...] = b0; o.fill_halo(1, "p")
     o.relax(1, 2)
     mg.nhydro.set_option("rbseq_fuse_min", 0)
+    mg.nhydro.set_option("rbseq_window", 0)
     mg.nhydro.set_option("rbseq_timeout_ms", 50)
     mg.nhydro.set_option("rbseq_test_stall", 1)
     try:
@@ -298,7 +300,84 @@ def test_rb_sequential_order_fused_launch_bounded_waits(mg):
         assert np.abs(g.get("p") - c).max() <= 1e-12 * np.abs(c).max()
     finally:
         mg.nhydro.set_option("rbseq_timeout_ms", 2000)
-        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20)
+        mg.nhydro.set_option("rbseq_fuse", 1); mg.nhydro.set_option("rbseq_fuse_min", 4 << 20); mg.nhydro.set_option("rbseq_window", 1)
+
+
+@pytest.mark.parametrize("dims,geom", [((32, 512, 16), "seamount"), ((64, 256, 32), "rndtopo"), ((48, 96, 16), "seamount"), ((16, 1024, 8), "seamount"),
+                                       ((144, 256, 8), "rndtopo")])
+def test_rb_sequential_order_windowed_walk(mg, dims, geom):
+    """Option "rbseq_window" (default 1): walk and correction of a colour in one launch without a walk over the whole level -- every workgroup
+    walks the m planes in front of its own over its chunk of columns +- 32, from zero (mgx_rbseq.hip: k_rbseq_window).  m comes from the
+    level's contraction bound rho = max |ag5| + |ag8| (found when the coefficients are built): rho^m <= 2^-64.  Checked here: the bound
+    against the same maximum formed from the oracle's coefficients, m against it, the colours really done that way, and three sweeps per level
+    from a rough random state against the oracle's sequential loop (1e-12 of max|p|) AND against the walk over the whole level
+    ("rbseq_window" = 0: 1e-14 -- a truncation of 2^-64 of the largest increment per colour)."""
+    nx, ny, nz = dims
+    o = _setup(mg, nx, ny, nz, geom, relax_method="RB")
+    rng = np.random.default_rng(47)
+    assert mg.nhydro.get_option("rbseq_window") == 1
+    for lev in range(1, o.nlevs + 1):
+        g = mg.grid(lev)
+        rho, m = mg.nhydro.rbseq_window_info(lev)
+        # the same bound from the oracle's coefficients: g1 = (T^-1 e1)(1) by tridiag's recurrences (mg_relax.f90:308-334), times cA(5|8,1,j,i)
+        cA = o.field("cA", lev)[1:-1, 1:-1]
+        d, dd = cA[..., 0], cA[..., 1]
+        n = d.shape[-1]
+        bet = 1.0 / d[..., 0]; x = np.zeros_like(d); gam = np.zeros_like(d); x[..., 0] = bet
+        for k in range(1, n):
+            gam[..., k] = dd[..., k] * bet
+            bet = 1.0 / (d[..., k] - dd[..., k] * gam[..., k])
+            x[..., k] = (0 - dd[..., k] * x[..., k - 1]) * bet
+        for k in range(n - 2, -1, -1):
+            x[..., k] -= gam[..., k + 1] * x[..., k + 1]
+        rho_o = (np.abs(x[..., 0] * cA[..., 0, 4]) + np.abs(x[..., 0] * cA[..., 0, 7])).max()
+        assert abs(rho - rho_o) <= 1e-12 * rho_o, (lev, rho, rho_o)
+        assert m >= 2 and rho ** m <= 2.0 ** -64 and (m == 2 or rho ** (m - 1) > 2.0 ** -64), (lev, rho, m)
+        p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+        o.field("p", lev)[...] = p; o.field("b", lev)[...] = b; o.fill_halo(lev, "p")
+        o.relax(lev, 3)
+        c = o.field("p", lev)
+        res = {}
+        for win in (0, 1):
+            mg.nhydro.set_option("rbseq_window", win)
+            try:
+                g.set("p", p); g.set("b", b); mg.fill_halo(lev, "p")
+                n0 = mg.nhydro.get_option("rbseq_window_colours")
+                mg.relax(lev, 3)
+                res[win] = (g.get("p"), mg.nhydro.get_option("rbseq_window_colours") - n0)
+            finally:
+                mg.nhydro.set_option("rbseq_window", 1)
+        assert res[0][1] == 0
+        # 3 sweeps x 2 colours; the one-workgroup levels (the coarsest ones) run the plane loop inside k_relax_wave instead
+        assert res[1][1] == 6 or (lev >= 2 and res[1][1] == 0 and g.nx * g.ny * g.nz <= 8192), (lev, res[1][1], g.nx, g.ny, g.nz)
+        assert np.abs(res[1][0] - c).max() <= 1e-12 * np.abs(c).max(), (lev, np.abs(res[1][0] - c).max() / np.abs(c).max())
+        assert np.abs(res[1][0] - res[0][0]).max() <= 1e-14 * np.abs(c).max(), (lev, np.abs(res[1][0] - res[0][0]).max() / np.abs(c).max())
+
+
+def test_rb_sequential_order_window_refused_when_the_walk_contracts_slowly(mg):
+    """A matrix whose same-colour couplings are strong (the oracle's coefficients with cA(5,1,:,:), cA(8,1,:,:) scaled up through set_field('cA')
+    until rho > 0.39): the bound asks for more than 48 planes of warm-up, the windowed walk is NOT used (planes = 0, no colour counted) and the
+    walk over the whole level gives the oracle's sequential-order result with the same matrix."""
+    nx, ny, nz = 32, 64, 16
+    o = _setup(mg, nx, ny, nz, "seamount", relax_method="RB")
+    rho0, m0 = mg.nhydro.rbseq_window_info(1)
+    assert 0 < rho0 < 0.1 and m0 > 0
+    f = 0.6 / rho0
+    cA = o.field("cA", 1)
+    cA[:, :, 0, 4] *= f; cA[:, :, 0, 7] *= f
+    mg.grid(1).set("cA", cA)
+    rho, m = mg.nhydro.rbseq_window_info(1)
+    assert abs(rho - 0.6) < 1e-9 and m == 0, (rho, m)
+    rng = np.random.default_rng(53)
+    g = mg.grid(1)
+    p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+    g.set("p", p); g.set("b", b); mg.fill_halo(1, "p")
+    o.field("p")[...] = p; o.field("b")[...] = b; o.fill_halo(1, "p")
+    n0 = mg.nhydro.get_option("rbseq_window_colours")
+    mg.relax(1, 2); o.relax(1, 2)
+    assert mg.nhydro.get_option("rbseq_window_colours") == n0
+    c = o.field("p")
+    assert np.abs(g.get("p") - c).max() <= 1e-12 * np.abs(c).max()
 
 
 @pytest.mark.parametrize("case", ["bmask", "tall", "stretched", "user_matrix"])

@@ -34,12 +34,12 @@ def test_documented_options_exist(built):
     from mgroms_amd._lib import lib
     hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
     names = set(re.findall(r'"([a-z_0-9]+)" \(default', hdr))
-    assert {"rb_seq", "rb_exact", "rbseq_fuse", "rbseq_fuse_min", "rbseq_d0_in_pass", "fuse_closing", "restrict_chain", "overlap", "async"} <= names, names
+    assert {"rb_seq", "rb_exact", "rbseq_fuse", "rbseq_window", "rbseq_fuse_min", "rbseq_d0_in_pass", "fuse_closing", "restrict_chain", "overlap", "async"} <= names, names
     L = lib()
     v = ctypes.c_int(-12345)
     for n in sorted(names - {"rbseq_timeout_ms", "ksp_timeout_ms", "p2p_timeout_ms"}):   # (device constants: write-only)
         assert L.mgx_get_option(n.encode(), ctypes.byref(v)) == 0, n
-    for n, d in (("rb_seq", 1), ("rb_exact", 0), ("rbseq_fuse", 1), ("rbseq_fuse_min", 4 << 20), ("rbseq_d0_in_pass", 1)):
+    for n, d in (("rb_seq", 1), ("rb_exact", 0), ("rbseq_fuse", 1), ("rbseq_window", 1), ("rbseq_fuse_min", 4 << 20), ("rbseq_d0_in_pass", 1)):
         assert L.mgx_get_option(n.encode(), ctypes.byref(v)) == 0 and v.value == d, (n, v.value)
 
 
