@@ -339,6 +339,9 @@ def main():
             sync()
             rb_it_ms = (time.perf_counter() - t4) / nit_rb * 1e3
             nhydro.set_option("warm_start", 0)
+            if mode == "sequential_order":
+                window_info = {f"level{l}": dict(zip(("rho", "planes"), nhydro.rbseq_window_info(l))) for l in range(1, mg.nlevs() + 1)}
+                window_info["colours_done_by_the_windowed_walk"] = nhydro.get_option("rbseq_window_colours")
             also_rb[mode] = {"vcycles_per_sec": 1e3 / rb_ms, "ms_per_step": rb_ms, "sweep_ms": rb_sweep, "solve_p_iteration_ms": rb_it_ms,
                              "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, "tolerance": tol}
         nhydro.set_option("rb_exact", 1)
@@ -350,8 +353,9 @@ def main():
         nhydro.set_option("rb_exact", 0); nhydro.set_option("rb_seq", 1)
         also_rb["sweep_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["sweep_ms"] / also_rb["parallel"]["sweep_ms"]
         also_rb["vcycle_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["ms_per_step"] / also_rb["parallel"]["ms_per_step"]
-        also_rb["sequential_order"]["how"] = ("per colour: parallel pass (writes the walk's d0), then the walk over the planes with the per-column correction chasing it inside the "
-                                              "same launch (level 1: forwarding waves + workers on the other XCDs; levels 3-4: every workgroup walks for itself); DESIGN.md 4.4")
+        also_rb["sequential_order"]["how"] = ("per colour: parallel pass (writes the walk's d0), then ONE launch in which every workgroup walks the m planes in front of its own from zero "
+                                              "(the walk contracts by rho per plane, rho^m <= 2^-64: option rbseq_window) and corrects its columns; DESIGN.md 4.4")
+        also_rb["sequential_order"]["window"] = window_info
 
     # HBM traffic of the dominant kernel from the PMC counters: they cannot be collected inside this run (rocprofv3 must wrap
     # the process, in passes of their own), so the figure is read from the committed capture of THIS command

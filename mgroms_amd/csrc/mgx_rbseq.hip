@@ -540,8 +540,10 @@ __global__ __launch_bounds__(256) void k_rbseq_walk_apply(LevView L, int rb, Sid
 // k_rbseq_apply.  Nothing is handed from one workgroup to another: no progress words, no forwarding waves, no placement assumption.
 // Where rho is too close to one (m > RBW_MAXM) the walk over the whole level stays (k_rbseq_scan).
 // Workgroup = chunk ch of plane i, rows [kz*4*KR, (kz+1)*4*KR): waves 0-3 hold KR rows each (KR = 16 at nz = 64 ... 1 at nz = 4), wave 4 walks.
-constexpr int RBW_MAXM = 48, RBW_D = 8;
-template <int CPL, int KR, bool SNAPW>
+constexpr int RBW_MAXM = 48;
+// Measured on level 1 of 512x512x64 (sweep of two passes + two of these launches, HIP events): ring depth 8 at 4 waves per SIMD 0.304-0.315 ms,
+// depth 4 or 2 at 5-6 waves per SIMD 0.304-0.313: the same -- the launch (~45 us for 201 MB) is the correction's traffic, not the walk.
+template <int CPL, int KR, bool SNAPW, int RBW_D = 8>
 __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz) {
   __shared__ double ul[64 * CPL + 2];   // u of plane i-1 over the window at 1 + (column - w0); a zero on either side
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1;
