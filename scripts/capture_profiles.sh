@@ -34,7 +34,14 @@ timeout -k 10 120 python3 $ROOT/scripts/tictoc_table.py $ROOT/profiles/${R}_tict
 # 6. red-black (the reference default) in its three modes, and the per-kernel time of a solve_p iteration in the sequential order
 timeout -k 10 200 python3 $ROOT/scripts/rb_modes_time.py 512 512 64 --json $ROOT/profiles/${R}_rb_modes_512.json > $OUT/${R}_rb_modes.log 2>&1 || exit 1
 timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $OUT/${R}_rbseq_solve -- python3 $ROOT/scripts/profile_solve.py 512 512 64 RB 5 > $OUT/${R}_rbseq_solve.log 2>&1 || exit 1
-python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_rbseq_solve/*/*_kernel_trace.csv | head -1) 5 bygrid > $ROOT/profiles/${R}_rbseq_solve_breakdown.txt || exit 1
+python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_rbseq_solve/*/*_kernel_trace.csv | head -1) 5 bygrid > $ROOT/profiles/${R}_rbseq_window_solve_breakdown.txt || exit 1
+# ... and with the walk over the whole level instead of the windowed walk (the fallback of a weakly contracting matrix)
+MGX_NO_RBSEQ_WINDOW=1 timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $OUT/${R}_rbseq_walk_solve -- python3 $ROOT/scripts/profile_solve.py 512 512 64 RB 5 > $OUT/${R}_rbseq_walk_solve.log 2>&1 || exit 1
+python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_rbseq_walk_solve/*/*_kernel_trace.csv | head -1) 5 bygrid > $ROOT/profiles/${R}_rbseq_solve_breakdown.txt || exit 1
+# 7. HBM traffic of the red-black kernels (two PMC passes over two solve_p iterations)
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_rb_fetch -- python3 $ROOT/scripts/profile_solve.py 512 512 64 RB 2 > $OUT/${R}_pmc_rb_fetch.log 2>&1 || exit 1
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_rb_write -- python3 $ROOT/scripts/profile_solve.py 512 512 64 RB 2 > $OUT/${R}_pmc_rb_write.log 2>&1 || exit 1
+python3 $ROOT/scripts/pmc_summary.py $(ls $OUT/${R}_pmc_rb_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${R}_pmc_rb_write/*/*_counter_collection.csv | head -1) 16777216 > $ROOT/profiles/${R}_pmc_traffic_rb_window.json || exit 1
 rm -f $OUT/${R}_*/*/*_kernel_trace.csv $OUT/${R}_*/*/*_counter_collection.csv
 mkdir -p $OUT/profiles_${R} && cp $ROOT/profiles/${R}_* $OUT/profiles_${R}/
 ls -la $OUT/profiles_${R}/

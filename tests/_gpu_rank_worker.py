@@ -102,6 +102,9 @@ def main():
         assert np.all(np.abs(hist - ho) <= 1e-13 + 1e-10 * np.abs(ho)), (hist, ho)
         pm, po = mg.grid(1).p, o.field("p", 1, rank)
         assert np.abs(pm - po).max() <= 1e-10 * np.abs(po).max(), (rank, np.abs(pm - po).max() / np.abs(po).max())
+        # ... by the windowed walk on the levels with neighbours too (u is zero in a halo plane: a rank's walk starts at its own plane 1
+        # or m planes back, whichever is later), unless this case asked for the launch with the hand-off
+        assert (nhydro.get_option("rbseq_window_colours") > 0) == (not fuse0), (rank, nhydro.get_option("rbseq_window_colours"))
     if golden:  # the reference's own recorded history for this decomposition (BASELINE.md 3.1, 2x2 column)
         import json
         with open(os.path.join(ROOT, "tests", "golden", "baseline_known_answers.json")) as f:
