@@ -255,6 +255,38 @@ def main():
     nhydro.set_option("warm_start", 0)
     mg.grid(1).set("p", p_keep_sp)
 
+    # The same two rates with the coarsest-level solve of a cycle as ONE matrix-vector product (option "coarsest_direct" = 2): the same
+    # linear map as the ns_coarsest sweeps in another association -- within 1e-12, NOT bit-identical -- so it is not what `value` measures (four
+    # colours keep their bit parity by default); reported beside it.  N = 1 only (a closed, un-gathered coarsest level).
+    also_direct = None
+    if world == 1 and int(os.environ.get("MGX_COARSEST_DIRECT", "1")) != 2:
+        nhydro.set_option("coarsest_direct", 2)
+        nhydro.set_option("async", 1)
+        p_keep_cd = mg.grid(1).p
+        for _ in range(2):
+            mg.Vcycle(1)
+        sync()
+        tcd = time.perf_counter()
+        for _ in range(args.steps):
+            mg.Vcycle(1)
+        sync()
+        cd_ms = (time.perf_counter() - tcd) / args.steps * 1e3
+        tcd = time.perf_counter()
+        for _ in range(nf):
+            mg.Fcycle()
+            mg.compute_residual(1)
+        sync()
+        cd_fc_rate = nf / (time.perf_counter() - tcd)
+        nhydro.synchronize()
+        nhydro.set_option("async", 0)
+        also_direct = {"vcycles_per_sec": 1e3 / cd_ms, "ms_per_step": cd_ms, "fcycle_iterations_per_sec": cd_fc_rate,
+                       "vcycle_roofline_frac": VCYCLE_BYTES_PER_CELL * cells / (cd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "fcycle_roofline_frac": FCYCLE_BYTES_PER_CELL * cells * cd_fc_rate / 1e9 / HBM_PEAK_GBS,
+                       "direct_solves": nhydro.get_option("coarsest_direct_solves"),
+                       "tolerance": "every level's p within 1e-12 of the sweeps' (tests/test_gpu_parity.py::test_coarsest_solve_as_one_matrix_vector_product); "
+                                    "the default (1) uses it for red-black in the sequential order only, so `value` is the bit-exact four-colour cycle"}
+        nhydro.set_option("coarsest_direct", 1)
+        mg.grid(1).set("p", p_keep_cd)
     counters_main, nlev_main = nhydro.counters(), mg.nlevs()
     # N>1: what one V-cycle exchanges on every rank, and what a level-1 / level-2 halo fill costs there (enqueued back to back, HIP stream time)
     exchange_report = None
@@ -416,7 +448,7 @@ def main():
             "solve_p_iterations_per_sec": sp_rate,
             "residual_before": res0, "residual_after": res1,
             "counters": counters_main,
-            "also_rb": also_rb,
+            "also_rb": also_rb, "also_coarsest_direct": also_direct,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, nz, args.method)

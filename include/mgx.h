@@ -187,6 +187,13 @@ int mgx_set_verbose(int level);
  *   0.03-0.04 on the seamount problem); otherwise, and with 0, the walk over the whole level ("rbseq_fuse").  Not the same bits as that
  *   walk (a truncation of 2^-64 of the largest increment), inside the same tolerances (tests: 1e-12 per relax call against "rb_exact").
  *   Read-only: "rbseq_window_colours" (colours done that way since mgx_init).
+ * "coarsest_direct" (default 1; MGX_COARSEST_DIRECT=n): inside a cycle the coarsest level is entered with p = 0 and left after relax(nlevs, ns_coarsest)
+ *   (mg_solvers.f90:117,144): a fixed linear map of b.  Its matrix is built with the level's own relax kernel from the unit vectors whenever the
+ *   coefficients change (lazily, at the first cycle after) and the solve becomes one matrix-vector product (mgx_relax_coarse.hip: k_coarse_direct; closed,
+ *   un-gathered coarsest levels of at most 2048 cells).  The same map in another association -- not the same bits as the sweeps (1e-15 of max|p|) -- so:
+ *   1 = only where the iteration is tolerance-based anyway (relax_method='RB', cmatrix='real' in the sequential order at speed, "rb_seq"), 2 = every method
+ *   (four colours then lose their bit parity with the reference's loop), 0 = never.  relax(nlevs, n) called as an operator always sweeps.
+ *   Read-only: "coarsest_direct_solves".
  * "rbseq_fuse_min" (default 4194304): cells of a colour (nx * ny/2 * nz) from which on a level counts as large for "rbseq_fuse".
  * "rbseq_timeout_ms" (default 2000; write-only): bound of the waits inside that launch.
  * "rbseq_d0_in_pass" (default 1): the colour pass also writes the walk's d0 (0 = a launch of its own; the same bits).

@@ -45,6 +45,10 @@ void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 void mgxk_rbseq_rho(hipStream_t, const LevView *, double *);
 int mgxk_rbseq_window_planes(double);
 int mgxk_rbseq_window(hipStream_t, const LevView *, int, Sides, int, int);
+int mgxk_coarse_direct_cells(const LevView *);
+int mgxk_coarse_direct_slabs(int);
+int mgxk_coarse_direct_build(hipStream_t, const LevView *, int, int, int, Sides, int, double *, long long, double *);
+int mgxk_coarse_direct_apply(hipStream_t, const LevView *, const double *, double *, unsigned int *, Sides);
 int mgxk_has_reg_kernel(const LevView *);
 int mgxk_residual_nblocks(const LevView *);
 void mgxk_residual(hipStream_t, const LevView *, double *, double *, int, int, Sides);
@@ -201,6 +205,14 @@ struct State {
   int rbseq_fuse_min = 4 << 20;  // option "rbseq_fuse_min": cells of a colour (nx * ny/2 * nz) from which on the fused launch is used (below, the hand-off costs more than the correction's own launch: 256x256x32 0.111 ms per sweep fused, 0.099 separate)
   int rbseq_d0_in_pass = 1;  // option "rbseq_d0_in_pass" (A/B): 0 = k_rbseq_d0 as a launch of its own
   int rbseq_test_stall = 0;  // test hook: the walk of the fused launch never reports its progress (the bounded waits must end the launch)
+  // option "coarsest_direct": the coarsest-level solve of a cycle (ns_coarsest sweeps from p = 0: a fixed linear map of b) as one matrix-vector product with the
+  // operator the level's own relax kernel builds from the unit vectors when the matrix changes (mgx_relax_coarse.hip: k_coarse_direct).  The same map in
+  // another association (1e-15 of max|p|), so: 1 (default) = only where the iteration is tolerance-based anyway (red-black in the sequential order at speed),
+  // 2 = every method (four colours then lose their bit parity with the reference's loop), 0 = never
+  int coarsest_direct = 1;
+  double *cd_pb = nullptr, *cd_M = nullptr, *cd_part = nullptr; unsigned int *cd_cnt = nullptr;
+  int cd_n = 0, cd_valid = 0, cd_method = -1, cd_mode = -1, cd_nsweeps = -1;   // cd_n: -1 = the level has no instance
+  long long n_direct = 0;   // coarsest solves done that way
   int rbseq_window = 1;  // option "rbseq_window" / MGX_NO_RBSEQ_WINDOW=1: walk and correction of a colour by the windowed walk (k_rbseq_window: no hand-off, no walk over the whole level) on the levels whose contraction bound allows it (Level::rbs_m)
   long long n_window = 0;  // colours done that way
   double *rho_dev = nullptr, rho_host[32];  // the levels' rho (k_rbseq_rho) on the device and after the set-up's copy
@@ -768,6 +780,33 @@ int relax_fused(int lev, int nsweeps, int flags) {
   return 1;
 }
 
+// relax(nlevs, ns_coarsest) inside a cycle (mg_solvers.f90:117,144), where the coarsest level is entered with p = 0 (fine2coarse, mg_intergrids.f90:70):
+// where option "coarsest_direct" allows it, one matrix-vector product with the operator the level's relax kernel built (mgx_relax_coarse.hip)
+int coarsest_solve() {
+  Level &L = S.lev[S.nlevs - 1];
+  const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
+  const int exact = S.method == M_RB && S.real && S.rb_exact, seq = S.method == M_RB && S.real && S.rb_seq && !exact && L.v.gk != nullptr;
+  const bool want = S.coarsest_direct == 2 || (S.coarsest_direct == 1 && seq);
+  if (want && S.nlevs >= 2 && S.use_small && !S.tictoc && S.method != M_GS && !exact && all_physical(ph) && !L.gather && S.par.ns_coarsest >= 1 && S.cd_n >= 0) {
+    const int n = mgxk_coarse_direct_cells(&L.v), mode = seq ? 2 : 0;
+    if (n > 0) {
+      if (!S.cd_M) {
+        CHK(dmalloc(&S.cd_pb, (size_t)2 * n * L.n3js)); CHK(dmalloc(&S.cd_M, (size_t)n * n));
+        CHK(dmalloc(&S.cd_part, (size_t)mgxk_coarse_direct_slabs(n) * n));
+        { double *q = nullptr; CHK(dmalloc(&q, 512)); S.cd_cnt = (unsigned int *)q; }   // one word per 64 rows, 64 bytes apart (zeroed by dmalloc)
+        S.cd_n = n;
+      }
+      if (!S.cd_valid || S.cd_method != S.method || S.cd_mode != mode || S.cd_nsweeps != S.par.ns_coarsest) {
+        if (mgxk_coarse_direct_build(S.stream, &L.v, S.par.ns_coarsest, S.method, S.real, ph, mode, S.cd_pb, (long long)L.n3js, S.cd_M)) {
+          S.cd_valid = 1; S.cd_method = S.method; S.cd_mode = mode; S.cd_nsweeps = S.par.ns_coarsest; S.n_launch += 3;
+        } else { S.cd_valid = 0; S.cd_n = -1; }   // no one-workgroup kernel for this level: the sweeps
+      }
+      if (S.cd_valid && mgxk_coarse_direct_apply(S.stream, &L.v, S.cd_M, S.cd_part, S.cd_cnt, ph)) { S.n_launch++; S.n_direct++; return 0; }
+    } else S.cd_n = -1;
+  }
+  return relax(S.nlevs, S.par.ns_coarsest);
+}
+
 // mg_solvers.f90:129-151.  lead_c2f: the caller is Fcycle, whose coarse2fine(lev1) comes right before (:119-120)
 int vcycle(int lev1, bool lead_c2f = false) {
   for (int lev = lev1; lev <= S.nlevs - 1; lev++) {
@@ -777,7 +816,7 @@ int vcycle(int lev1, bool lead_c2f = false) {
     CHK(relax(lev, S.par.ns_pre));
     CHK(fine2coarse(lev, false, true));  // compute_residual(lev) + fine2coarse(lev)
   }
-  CHK(relax(S.nlevs, S.par.ns_coarsest));
+  CHK(coarsest_solve());
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
     if (relax_fused(lev, S.par.ns_post, 1)) continue;
     CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_post >= 1));
@@ -832,7 +871,7 @@ int fcycle(bool have_r2 = false) {
     }
     CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
-  CHK(relax(S.nlevs, S.par.ns_coarsest));
+  CHK(coarsest_solve());
   for (int lev = S.nlevs - 1; lev >= 1; lev--) CHK(vcycle(lev, true));  // coarse2fine(lev) + Vcycle(lev), :119-120
   return 0;
 }
@@ -1010,6 +1049,7 @@ int define_matrices() {
   if (S.rho_dev) HIPCHK(hipMemcpyAsync(S.rho_host, S.rho_dev, sizeof S.rho_host, hipMemcpyDeviceToHost, S.stream));
   CHK(sync_stream());
   set_window_planes();
+  S.cd_valid = 0;
   S.have_matrix = true;
   return 0;
 }
@@ -1405,7 +1445,7 @@ void mgx_clean(void) {
   if (S.ev_s) (void)hipEventDestroy(S.ev_s);
   if (S.ev_x) (void)hipEventDestroy(S.ev_x);
   tt_collect();
-  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, rf = S.rbseq_fuse, rw = S.rbseq_window, rfm = S.rbseq_fuse_min, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
+  hipStream_t st = S.stream; int vb = S.verbose, ws = S.warm_start, tc = S.tictoc, eh = S.exact_halos, rx = S.rb_exact, rq = S.rb_seq, kr = S.keep_r, cs = S.c2f_skip, fc = S.fuse_closing, uc = S.use_chain, rf = S.rbseq_fuse, rw = S.rbseq_window, cdo = S.coarsest_direct, rfm = S.rbseq_fuse_min, ovl = S.overlap, kp = S.use_ksp, fz = S.use_fuse, ao = S.async_ops;
   mgx_exchange_fn ex = S.ex; mgx_allreduce_fn ar = S.ar; mgx_allgather_fn ag = S.ag; void *ctx = S.ctx; const bool nat = S.native_rccl;
   // the timer table is module state of mg_tictoc in the reference: it outlives nhydro_clean (the drivers print it afterwards, mg_testseamount.f90:220-221)
   std::vector<std::string> tn = S.tt_names; std::vector<HostTic> th = S.tt_host; const int tnb = S.tt_nblev;
@@ -1414,7 +1454,7 @@ void mgx_clean(void) {
   S = State();
   S.tt_names = tn; S.tt_host = th; S.tt_nblev = tnb; memcpy(S.tt_time, tsave, sizeof tsave); memcpy(S.tt_calls, csave, sizeof csave);
   S.native_rccl = nat;
-  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.rbseq_fuse = rf; S.rbseq_window = rw; S.rbseq_fuse_min = rfm; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
+  S.stream = st; S.verbose = vb; S.warm_start = ws; S.tictoc = tc; S.exact_halos = eh; S.rb_exact = rx; S.rb_seq = rq; S.keep_r = kr; S.c2f_skip = cs; S.fuse_closing = fc; S.use_chain = uc; S.rbseq_fuse = rf; S.rbseq_window = rw; S.coarsest_direct = cdo; S.rbseq_fuse_min = rfm; S.overlap = ovl; S.use_ksp = kp; S.use_fuse = fz; S.async_ops = ao; S.ex = ex; S.ar = ar; S.ag = ag; S.ctx = ctx;
 }
 
 int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_params *par) {
@@ -1546,6 +1586,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
   if (getenv("MGX_NO_RESTRICT_CHAIN")) S.use_chain = 0;
   if (getenv("MGX_NO_RBSEQ_FUSE")) S.rbseq_fuse = 0;
   if (getenv("MGX_NO_RBSEQ_WINDOW")) S.rbseq_window = 0;
+  if (getenv("MGX_COARSEST_DIRECT")) S.coarsest_direct = atoi(getenv("MGX_COARSEST_DIRECT"));
   if (getenv("MGX_OVERLAP")) S.overlap = atoi(getenv("MGX_OVERLAP"));
   if (getenv("MGX_NO_KSP")) S.use_ksp = 0;
   if (getenv("MGX_P2P_TIMEOUT_MS")) (void)mgxk_set_p2p_timeout(atof(getenv("MGX_P2P_TIMEOUT_MS")));
@@ -1727,6 +1768,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "restrict_chain")) S.use_chain = value;
   else if (streq(name, "rbseq_fuse")) S.rbseq_fuse = value;
   else if (streq(name, "rbseq_window")) S.rbseq_window = value;
+  else if (streq(name, "coarsest_direct")) S.coarsest_direct = value;
   else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
   else if (streq(name, "async")) S.async_ops = value;
@@ -1774,6 +1816,8 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "restrict_chain")) *value = S.use_chain;
   else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
   else if (streq(name, "rbseq_window")) *value = S.rbseq_window;
+  else if (streq(name, "coarsest_direct")) *value = S.coarsest_direct;
+  else if (streq(name, "coarsest_direct_solves")) *value = (int)S.n_direct;
   else if (streq(name, "rbseq_window_colours")) *value = (int)S.n_window;
   else if (streq(name, "rbseq_fuse_min")) *value = S.rbseq_fuse_min;
   else if (streq(name, "rbseq_d0_in_pass")) *value = S.rbseq_d0_in_pass;
@@ -1905,6 +1949,7 @@ int mgx_set_field(int lev, int field, const double *host) {
     }
     L.v.zy = L.v.zx = nullptr;  // a user-supplied matrix is used as stored
     L.v.m4 = nullptr;
+    S.cd_valid = 0;
     S.have_matrix = true;
   } else if (!field_ptr(L, field, &a, &n)) {
     HIPCHK(hipMemcpyAsync(a, host, n * sizeof(double), hipMemcpyHostToDevice, S.stream));

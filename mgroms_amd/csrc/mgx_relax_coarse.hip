@@ -26,8 +26,10 @@
 // SEQ: red-black in the reference's sequential order (the walk below; REAL only) -- its own instances, so that the others keep their registers
 struct VecD4 { double v[4]; };
 template <int NZ, bool REAL, int NT, bool FZ = false, bool SEQ = false>
-__global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph, LevView C, int flags) {
+__global__ __launch_bounds__(NT, 1) void k_relax_wave(LevView G, int nsweeps, int method, Sides ph, LevView C, int flags, long long bstride) {
   constexpr bool seq = SEQ && REAL;
+  // a batch of independent solves with the level's matrix (mgxk_coarse_direct_build): workgroup q works on its own p and b
+  if (bstride) { G.p += (long long)blockIdx.x * bstride; G.b += (long long)blockIdx.x * bstride; }
   extern __shared__ double ldsw[];
   const int nx = G.nx, ny = G.ny, W = ny, PL = nx * ny;  // P[k][i-1][j-1], interior only
   double *__restrict__ P = ldsw, *__restrict__ P1 = ldsw + NZ * PL;  // P1: k=1 snapshot of the parallel red-black pass
@@ -367,7 +369,7 @@ extern "C" {
 // Cv, flags: see k_relax_wave (0 / nullptr = the plain relax call); mgxk_relax_wave_fused is the entry the cycles use
 // mode (red-black with cmatrix='real' only): 0 = parallel colour passes, 1 = the bit-exact plane loop (not here: k_relax_reg), 2 = the
 // reference's sequential order by the walk (k_relax_wave's seq)
-static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode, const LevView *Cv, int flags) {
+static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode, const LevView *Cv, int flags, int nbatch = 1, long long bstride = 0) {
   mgx_before_launch();
   static const bool off = getenv("MGX_NO_WAVE") != nullptr, off4 = getenv("MGX_NO_WAVE4") != nullptr, off8 = getenv("MGX_NO_WAVE8") != nullptr;
   if (off || (L->nz != 2 && L->nz != 4) || method == 0 || (mode == 1 && method == 1 && real)) return 0;
@@ -387,15 +389,15 @@ static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int 
     if (bytes > granted) { if (hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; } granted = 160 * 1024; } }
 #define WAVE_CASE(NZV, NTV)                                                                                                   \
   { if (seq) { WAVE_LDS((k_relax_wave<NZV, true, NTV, false, true>))                                                           \
-      hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV, false, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); } \
-    else if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); \
-    else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);          \
+      hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV, false, true>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride); } \
+    else if (real) hipLaunchKernelGGL((k_relax_wave<NZV, true, NTV>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride); \
+    else hipLaunchKernelGGL((k_relax_wave<NZV, false, NTV>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride);          \
     return mgx_launched(); }
 #define WAVE_CASE_FZ(NTV)                                                                                                     \
   { if (seq) { WAVE_LDS((k_relax_wave<4, true, NTV, true, true>))                                                              \
-      hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); } \
-    else if (real) hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags); \
-    else hipLaunchKernelGGL((k_relax_wave<4, false, NTV, true>), dim3(1), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags);      \
+      hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true, true>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride); } \
+    else if (real) hipLaunchKernelGGL((k_relax_wave<4, true, NTV, true>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride); \
+    else hipLaunchKernelGGL((k_relax_wave<4, false, NTV, true>), dim3(nbatch), dim3(NTV), bytes, st, *L, nsweeps, method, ph, Cc, flags, bstride);      \
     return mgx_launched(); }
   if (flags & 3) {
     if (L->nz != 4) return 0;
@@ -411,6 +413,93 @@ static int relax_wave_launch(hipStream_t st, const LevView *L, int nsweeps, int 
 int mgxk_relax_wave(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode) {
   return relax_wave_launch(st, L, nsweeps, method, real, ph, mode, nullptr, 0);
 }
+// ---- the coarsest-level solve of a cycle as ONE matrix-vector product (option "coarsest_direct") -----------------------------------
+// Inside a cycle the coarsest level is entered with p = 0 (fine2coarse, mg_intergrids.f90:70) and left after relax(nlevs, ns_coarsest)
+// (mg_solvers.f90:117,144): ns_coarsest sweeps of a FIXED linear iteration from zero, i.e. p = B b with B = (sum_k R^k) N a property of
+// the level's matrix alone.  B is built when the coefficients are (mgxk_coarse_direct_build): the n = nx ny nz unit vectors are relaxed as a
+// batch by the very kernel that serves the level (k_relax_wave, one workgroup per unit vector: two rounds of workgroups on the 256 CUs for the
+// 512 cells of 16x16x2), so that every column of B holds that kernel's own bits; k_coarse_direct then forms p = B b (n^2 multiply-adds spread
+// over n / 64 x n / 64 one-wave workgroups; partial sums combined by the last workgroup of each row tile in a fixed order: deterministic) and stores p
+// with its physical mirrors.  ~7 us instead of 121 (red-black in the sequential order) / 34 (four colours) for the 160 / 80 dependent colour
+// passes of the 16x16x2 level.  The same linear map in another association: NOT the same bits as the sweeps (1e-15 of max|p|; tests: 1e-12),
+// which is why the default uses it only where the iteration is tolerance-based anyway (red-black in the sequential order at speed).
+constexpr int CDB = 64, CDT = 64;   // columns and rows of B per workgroup (one wave)
+__device__ __forceinline__ void cd_cell(const LevView &L, int r, int *k0, int *j, int *i) { *k0 = r % L.nz; const int q = r / L.nz; *j = 1 + q % L.ny; *i = 1 + q / L.ny; }
+__device__ __forceinline__ long long cd_js(const LevView &L, int r) { int k0, j, i; cd_cell(L, r, &k0, &j, &i); return (long long)i * L.plane + (long long)k0 * L.RS + jpos(L, j); }
+// batch set-up: workgroup c zeroes its p and b and sets b = e_c
+__global__ void k_cd_init(LevView L, double *pb, long long stride, int n) {
+  const int c = blockIdx.x;
+  double *pp = pb + (long long)c * stride, *bb = pb + (long long)(n + c) * stride;
+  for (long long t = threadIdx.x; t < stride; t += blockDim.x) { pp[t] = 0.0; bb[t] = 0.0; }
+  __syncthreads();
+  if (threadIdx.x == 0) bb[cd_js(L, c)] = 1.0;
+}
+// M[c * n + r] = column c of B at cell r
+__global__ void k_cd_compact(LevView L, const double *pb, long long stride, double *M, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (r < n) M[(long long)c * n + r] = pb[(long long)c * stride + cd_js(L, r)];
+}
+// One wave = CDT rows x CDB columns of B.  The tickets of a row tile are atomics on ONE word, which the memory side serialises (~0.4 us each with the
+// workgroups spread over the eight XCDs: the first version, 64 slabs of 8 columns, spent 26 us there): few, wide slabs, one word per 64-byte line.
+__global__ __launch_bounds__(CDT) void k_coarse_direct(LevView L, const double *__restrict__ M, double *part, unsigned int *cnt, Sides ph, int n) {
+  __shared__ double bs[CDB];
+  __shared__ int last;
+  const int r = blockIdx.x * CDT + threadIdx.x, c0 = blockIdx.y * CDB, nslab = gridDim.y;
+  const int rc = r < n ? r : n - 1;
+  for (int t = threadIdx.x; t < CDB; t += CDT) bs[t] = c0 + t < n ? L.b[cd_js(L, c0 + t)] : 0.0;
+  double m[CDB];
+#pragma unroll
+  for (int t = 0; t < CDB; t++) { const int c = c0 + t < n ? c0 + t : n - 1; m[t] = M[(long long)c * n + rc]; }   // (columns past n meet b = 0)
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < CDB; t++) acc += m[t] * bs[t];
+  if (r < n) part[(long long)blockIdx.y * n + r] = acc;
+  __threadfence();   // release: this workgroup's partial sums before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(cnt + blockIdx.x * 16, 1u) == (unsigned int)(nslab - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();   // acquire: every slab's partial sums of this row tile
+  if (threadIdx.x == 0) cnt[blockIdx.x * 16] = 0;   // for the next call (calls on one level are ordered by the stream)
+  if (r >= n) return;
+  double v = 0.0;
+  for (int sl = 0; sl < nslab; sl++) v += __hip_atomic_load(part + (long long)sl * n + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int k0, j, i;
+  cd_cell(L, r, &k0, &j, &i);
+  const int c = jpos(L, j);
+  const long long ro = (long long)k0 * L.RS;
+  L.p[(long long)i * L.plane + ro + c] = v;
+  mirror_store(L, L.p, ro, j, i, c, v, ph);
+}
+
+// cells of a level the direct solve serves (a closed level of the one-workgroup kernel, at most 2048 cells), 0 = none
+int mgxk_coarse_direct_cells(const LevView *L) {
+  const long long n = (long long)L->nx * L->ny * L->nz;
+  return ((L->nz == 2 || L->nz == 4) && n <= 2048 && !(L->nx & 1) && !(L->ny & 1)) ? (int)n : 0;
+}
+// build B (M: n * n doubles) with the level's own relax kernel; pb: scratch of 2 * n * stride doubles (stride = the level's array size).
+// Returns 1 when built (all of it enqueued on st), 0 = the level has no one-workgroup kernel for this method / mode.
+int mgxk_coarse_direct_build(hipStream_t st, const LevView *L, int nsweeps, int method, int real, Sides ph, int mode, double *pb, long long stride, double *M) {
+  const int n = mgxk_coarse_direct_cells(L);
+  if (!n || nsweeps < 1) return 0;
+  hipLaunchKernelGGL(k_cd_init, dim3(n), dim3(256), 0, st, *L, pb, stride, n);
+  LevView B = *L;
+  B.p = pb; B.b = pb + (long long)n * stride;
+  if (!relax_wave_launch(st, &B, nsweeps, method, real, ph, mode, nullptr, 0, n, stride)) return 0;
+  hipLaunchKernelGGL(k_cd_compact, dim3((n + 255) / 256, n), dim3(256), 0, st, *L, pb, stride, M, n);
+  return mgx_launched();
+}
+// p = B b with the mirrors; part: (n / CDB rounded up) * n doubles, cnt: one word per 64 rows, 64 bytes apart, zero before the first call
+int mgxk_coarse_direct_apply(hipStream_t st, const LevView *L, const double *M, double *part, unsigned int *cnt, Sides ph) {
+  const int n = mgxk_coarse_direct_cells(L);
+  if (!n) return 0;
+  mgx_before_launch();
+  hipLaunchKernelGGL(k_coarse_direct, dim3((n + CDT - 1) / CDT, (n + CDB - 1) / CDB), dim3(CDT), 0, st, *L, M, part, cnt, ph, n);
+  return mgx_launched();
+}
+int mgxk_coarse_direct_slabs(int n) { return (n + CDB - 1) / CDB; }
+
 // relax(lev, nsweeps) of a closed level the one-workgroup kernel serves, with coarse2fine(lev) folded in front (flags & 1) and / or
 // compute_residual(lev) + fine2coarse(lev) folded behind (flags & 2); C = level lev+1 (closed, exactly half the size, not gathered).
 // Returns 1 when launched, 0 = the caller runs the separate operators.

@@ -380,6 +380,64 @@ def test_rb_sequential_order_window_refused_when_the_walk_contracts_slowly(mg):
     assert np.abs(g.get("p") - c).max() <= 1e-12 * np.abs(c).max()
 
 
+@pytest.mark.parametrize("method,dims,geom", [("RB", (64, 64, 16), "seamount"), ("RB", (128, 256, 32), "rndtopo"), ("FC", (128, 128, 16), "seamount"),
+                                              ("FC", (64, 128, 32), "rndtopo"), ("RB", (32, 32, 4), "seamount")])
+def test_coarsest_solve_as_one_matrix_vector_product(mg, method, dims, geom):
+    """Option "coarsest_direct": inside a cycle the coarsest level is entered with p = 0 and left after ns_coarsest sweeps -- a fixed linear map of b,
+    whose matrix the level's own relax kernel builds from the unit vectors (lazily, after the coefficients changed) and which then costs one
+    matrix-vector product (mgx_relax_coarse.hip: k_coarse_direct).  Default 1: used for red-black in the sequential order (a tolerance-based iteration
+    anyway), NOT for four colours (bit parity kept).  Checked: two cycles from a random right-hand side with the option off, at its default and forced
+    (2) -- every level's p within 1e-12 of the sweeps' (the same map in another association), bit for bit where the default must not use it; the
+    counter of direct solves; a rebuild after the matrix changed (set_field('cA') of the coarsest level: scaled coefficients, another map); and the
+    oracle's two cycles within 1e-12."""
+    nx, ny, nz = dims
+    o = _setup(mg, nx, ny, nz, geom, relax_method=method)
+    rng = np.random.default_rng(59)
+    g1 = mg.grid(1)
+    b = rng.standard_normal(g1._shape("b"))
+    o.field("b")[...] = b; o.field("p")[...] = 0.0
+    o.vcycle(1); o.vcycle(1)
+
+    def run(opt):
+        mg.nhydro.set_option("coarsest_direct", opt)
+        try:
+            g1.set("b", b); g1.set("p", np.zeros(g1._shape("p")))
+            n0 = mg.nhydro.get_option("coarsest_direct_solves")
+            mg.Vcycle(1); mg.Vcycle(1)
+            return [mg.grid(l).get("p") for l in range(1, o.nlevs + 1)], mg.nhydro.get_option("coarsest_direct_solves") - n0
+        finally:
+            mg.nhydro.set_option("coarsest_direct", 1)
+
+    off, n_off = run(0)
+    dflt, n_dflt = run(1)
+    forced, n_forced = run(2)
+    assert n_off == 0 and n_forced == 2 and n_dflt == (2 if method == "RB" else 0), (n_off, n_dflt, n_forced)
+    tol_o = 1e-12 if method == "FC" else 1e-10    # (the sequential-order red-black is itself a few ulp per sweep from the oracle's loop)
+    for l in range(o.nlevs):
+        ref = np.abs(off[l]).max()
+        assert np.abs(forced[l] - off[l]).max() <= 1e-12 * ref, (l + 1, np.abs(forced[l] - off[l]).max() / ref)
+        assert np.abs(off[l] - o.field("p", l + 1)).max() <= tol_o * ref, (l + 1, np.abs(off[l] - o.field("p", l + 1)).max() / ref)
+        assert np.abs(forced[l] - o.field("p", l + 1)).max() <= tol_o * ref
+        if method == "FC":
+            assert np.array_equal(dflt[l], off[l]) and np.array_equal(off[l], o.field("p", l + 1)), l + 1   # four colours: the reference's bits by default
+        else:
+            assert np.array_equal(dflt[l], forced[l]), l + 1
+    assert np.abs(forced[-1]).max() > 0
+    # another matrix on the coarsest level: the operator is rebuilt (the direct solve follows the sweeps of the NEW matrix)
+    gc = mg.grid(o.nlevs)
+    cA = o.field("cA", o.nlevs).copy()
+    cA[..., 0] *= 1.5
+    gc.set("cA", cA)
+    off2, _ = run(0)
+    forced2, n2 = run(2)
+    assert n2 == 2
+    refc = np.abs(off2[-1]).max()
+    assert np.abs(off2[-1] - off[-1]).max() > 1e-2 * refc     # the change is visible in the coarsest level's solution ...
+    for l in range(o.nlevs):                                  # ... and the direct solve has followed it
+        ref = np.abs(off2[l]).max()
+        assert np.abs(forced2[l] - off2[l]).max() <= 1e-12 * ref, (l + 1, np.abs(forced2[l] - off2[l]).max() / ref)
+
+
 @pytest.mark.parametrize("case", ["bmask", "tall", "stretched", "user_matrix"])
 def test_rb_sequential_order_other_coefficient_paths(mg, case):
     """The sequential-order red-black (default) where the colour pass runs other kernels / other coefficients than the seamount's matrix-free
