@@ -542,9 +542,11 @@ __global__ __launch_bounds__(256) void k_rbseq_walk_apply(LevView L, int rb, Sid
 // Workgroup = chunk ch of plane i, rows [kz*4*KR, (kz+1)*4*KR): waves 0-3 hold KR rows each (KR = 16 at nz = 64 ... 1 at nz = 4), wave 4 walks.
 constexpr int RBW_MAXM = 48;
 // Measured on level 1 of 512x512x64 (sweep of two passes + two of these launches, HIP events): ring depth 8 at 4 waves per SIMD 0.304-0.315 ms,
-// depth 4 or 2 at 5-6 waves per SIMD 0.304-0.313: the same -- the launch (~45 us for 201 MB) is the correction's traffic, not the walk.
+// depth 4 or 2 at 5-6 waves per SIMD 0.304-0.313: the same.  With no plane walked at all (timing probe MGX_RBW_PROBE_M=0) 0.295-0.296, with 14 planes
+// 0.306-0.310: the walk costs ~6 us of the launch's ~45 (201 MB algorithmic, 210 MB counted: profiles/r04_pmc_traffic_rb_window.json) -- the dependent
+// chain of 14 steps in ONE wave that shares its SIMD's issue slots with three row waves; at raised priority (s_setprio) ~4 of the 6 come back.
 template <int CPL, int KR, bool SNAPW, int RBW_D = 8>
-__global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz) {
+__global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz, int prio) {
   __shared__ double ul[64 * CPL + 2];   // u of plane i-1 over the window at 1 + (column - w0); a zero on either side
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1;
   // block -> (chunk, plane, row group).  XCD-aware where the planes divide by 8 (xmap): workgroup b runs on XCD b % 8, which takes a contiguous
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides p
   const int k0 = (kz * 4 + (wv & 3)) * KR;
   double pv[KR], gv[KR], c5 = 0.0, c8 = 0.0;
   if (wv == 4) {
+    if (prio) __builtin_amdgcn_s_setprio(3);   // the workgroup waits for this wave's dependent chain: let it issue ahead of the row waves
     double up[CPL];
     bool ok[CPL];
     int jc[CPL];
@@ -842,12 +845,16 @@ int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int sn
   if (!kr || nz / (4 * kr) > 65535) return 0;
   mgx_before_launch();
   static const bool no_xmap = getenv("MGX_RBSEQ_WINDOW_NO_XMAP") != nullptr;   // A/B
+  // the walking wave at raised priority (s_setprio 3): level-1 sweep 0.3075-0.3150 -> 0.2989-0.3073 ms (three runs each, alternating); MGX_RBW_PRIO=0: A/B
+  static const int prio = getenv("MGX_RBW_PRIO") ? atoi(getenv("MGX_RBW_PRIO")) : 1;
+  static const int probe_m = getenv("MGX_RBW_PROBE_M") ? atoi(getenv("MGX_RBW_PROBE_M")) : -1;   // timing probe only (wrong results): another number of planes walked
+  if (probe_m >= 0) m = probe_m;
   const int nt = level_streams(L), cpl = nyh <= WAVE ? 1 : 2, nch = (nyh + WAVE - 1) / WAVE, nkz = nz / (4 * kr);
   const int xmap = !no_xmap && L->nx % 8 == 0 && (long long)nch * L->nx * nkz < (1LL << 31);
   const dim3 grd = xmap ? dim3(nch * L->nx * nkz) : dim3(nch, L->nx, nkz), blk(320);
 #define WIN_CASE(CPLV, KRV)                                                                                          \
-  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz); \
-    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz); }
+  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio); \
+    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio); }
 #define WIN_KR(CPLV) { if (kr == 16) WIN_CASE(CPLV, 16) else if (kr == 8) WIN_CASE(CPLV, 8) else if (kr == 4) WIN_CASE(CPLV, 4) else if (kr == 2) WIN_CASE(CPLV, 2) else WIN_CASE(CPLV, 1) }
   if (cpl == 1) WIN_KR(1) else WIN_KR(2)
 #undef WIN_KR
