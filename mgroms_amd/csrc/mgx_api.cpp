@@ -782,12 +782,13 @@ int relax_fused(int lev, int nsweeps, int flags) {
 
 // relax(nlevs, ns_coarsest) inside a cycle (mg_solvers.f90:117,144), where the coarsest level is entered with p = 0 (fine2coarse, mg_intergrids.f90:70):
 // where option "coarsest_direct" allows it, one matrix-vector product with the operator the level's relax kernel built (mgx_relax_coarse.hip)
-int coarsest_solve() {
+// p_zero: the caller has just restricted onto the level (Vcycle(nlevs) called as an operator relaxes whatever p it finds: the sweeps)
+int coarsest_solve(bool p_zero) {
   Level &L = S.lev[S.nlevs - 1];
   const Sides ph = {L.neighb[0] < 0, L.neighb[1] < 0, L.neighb[2] < 0, L.neighb[3] < 0};
   const int exact = S.method == M_RB && S.real && S.rb_exact, seq = S.method == M_RB && S.real && S.rb_seq && !exact && L.v.gk != nullptr;
   const bool want = S.coarsest_direct == 2 || (S.coarsest_direct == 1 && seq);
-  if (want && S.nlevs >= 2 && S.use_small && !S.tictoc && S.method != M_GS && !exact && all_physical(ph) && !L.gather && S.par.ns_coarsest >= 1 && S.cd_n >= 0) {
+  if (want && p_zero && S.nlevs >= 2 && S.use_small && !S.tictoc && S.method != M_GS && !exact && all_physical(ph) && !L.gather && S.par.ns_coarsest >= 1 && S.cd_n >= 0) {
     const int n = mgxk_coarse_direct_cells(&L.v), mode = seq ? 2 : 0;
     if (n > 0) {
       if (!S.cd_M) {
@@ -816,7 +817,7 @@ int vcycle(int lev1, bool lead_c2f = false) {
     CHK(relax(lev, S.par.ns_pre));
     CHK(fine2coarse(lev, false, true));  // compute_residual(lev) + fine2coarse(lev)
   }
-  CHK(coarsest_solve());
+  CHK(coarsest_solve(lev1 < S.nlevs));
   for (int lev = S.nlevs - 1; lev >= lev1; lev--) {
     if (relax_fused(lev, S.par.ns_post, 1)) continue;
     CHK(coarse2fine(lev, S.exact_halos || S.keep_r, S.c2f_skip && S.method == M_FC && S.par.ns_post >= 1));
@@ -871,7 +872,7 @@ int fcycle(bool have_r2 = false) {
     }
     CHK(fine2coarse(lev, true));  // + grid(lev+1)%r = grid(lev+1)%b (mg_solvers.f90:113)
   }
-  CHK(coarsest_solve());
+  CHK(coarsest_solve(S.nlevs >= 2));
   for (int lev = S.nlevs - 1; lev >= 1; lev--) CHK(vcycle(lev, true));  // coarse2fine(lev) + Vcycle(lev), :119-120
   return 0;
 }

@@ -423,6 +423,22 @@ def test_coarsest_solve_as_one_matrix_vector_product(mg, method, dims, geom):
         else:
             assert np.array_equal(dflt[l], forced[l]), l + 1
     assert np.abs(forced[-1]).max() > 0
+    # Vcycle(nlevs) called as an operator relaxes the p it finds (no restriction in front): the sweeps, whatever the option says
+    gq = mg.grid(o.nlevs)
+    pq = rng.standard_normal(gq._shape("p")); bq = rng.standard_normal(gq._shape("b"))
+    mg.nhydro.set_option("coarsest_direct", 2)
+    try:
+        gq.set("p", pq); gq.set("b", bq); mg.fill_halo(o.nlevs, "p")
+        nq = mg.nhydro.get_option("coarsest_direct_solves")
+        mg.Vcycle(o.nlevs)
+        assert mg.nhydro.get_option("coarsest_direct_solves") == nq
+        got_q = gq.get("p")
+    finally:
+        mg.nhydro.set_option("coarsest_direct", 1)
+    o.field("p", o.nlevs)[...] = pq; o.field("b", o.nlevs)[...] = bq; o.fill_halo(o.nlevs, "p")
+    o.vcycle(o.nlevs)
+    cq = o.field("p", o.nlevs)
+    assert np.abs(got_q - cq).max() <= (1e-12 if method == "FC" else 1e-10) * np.abs(cq).max()
     # another matrix on the coarsest level: the operator is rebuilt (the direct solve follows the sweeps of the NEW matrix)
     gc = mg.grid(o.nlevs)
     cA = o.field("cA", o.nlevs).copy()
