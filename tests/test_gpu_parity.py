@@ -304,14 +304,15 @@ def test_rb_sequential_order_fused_launch_bounded_waits(mg):
 
 
 @pytest.mark.parametrize("dims,geom", [((32, 512, 16), "seamount"), ((64, 256, 32), "rndtopo"), ((48, 96, 16), "seamount"), ((16, 1024, 8), "seamount"),
-                                       ((144, 256, 8), "rndtopo")])
+                                       ((144, 256, 8), "rndtopo"), ((48, 160, 16), "rndtopo"), ((20, 160, 4), "seamount")])
 def test_rb_sequential_order_windowed_walk(mg, dims, geom):
     """Option "rbseq_window" (default 1): walk and correction of a colour in one launch without a walk over the whole level -- every workgroup
     walks the m planes in front of its own over its chunk of columns +- 32, from zero (mgx_rbseq.hip: k_rbseq_window).  m comes from the
     level's contraction bound rho = max |ag5| + |ag8| (found when the coefficients are built): rho^m <= 2^-64.  Checked here: the bound
     against the same maximum formed from the oracle's coefficients, m against it, the colours really done that way, and three sweeps per level
     from a rough random state against the oracle's sequential loop (1e-12 of max|p|) AND against the walk over the whole level
-    ("rbseq_window" = 0: 1e-14 -- a truncation of 2^-64 of the largest increment per colour)."""
+    ("rbseq_window" = 0: 1e-14 -- a truncation of 2^-64 of the largest increment per colour).  Shapes: half-rows of 256 / 128 / 48 / 512 columns, ragged
+    ones (80 = a full chunk + 16 columns, 40), a plane count that is not a multiple of 8 (plain block order), nz = 4 (one row per wave)."""
     nx, ny, nz = dims
     o = _setup(mg, nx, ny, nz, geom, relax_method="RB")
     rng = np.random.default_rng(47)
