@@ -69,6 +69,44 @@ def cpu_baseline(nx, ny, nz, method, cycles=2):
             "level1_sweep_GBs": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / sweep / 1e9}
 
 
+def live_traffic(nx, ny, nz, method, kname):
+    """HBM bytes per launch of the level-1 colour pass from the PMC counters, measured in THIS invocation: two rocprofv3 passes (FETCH_SIZE,
+    WRITE_SIZE -- they do not fit one pass) over a child process that runs a few level-1 sweeps of the same workload (scripts/sweep_time.py),
+    started BEFORE this process touches the GPU; FETCH x 2 (the guide's gfx950 correction, scripts/pmc_summary.py), WRITE exact, the largest
+    dispatch of the kernel.  None when rocprofv3 is missing, this process is itself being profiled, or a pass fails / times out: the line then
+    falls back to the committed capture and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="mgx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "sweep_time.py"), str(nx), str(ny), str(nz), method, "3"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            best = 0.0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and row["Kernel_Name"].split("(")[0].replace("void ", "") == kname:
+                    best = max(best, float(row["Counter_Value"]))
+            if best <= 0.0:
+                return None
+            vals[counter] = best
+        return 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _spawn_ranks(n):
     """`python bench.py --gpus N` from a bare shell: start the N ranks as fresh child processes through
     torch.distributed.run BEFORE this process touches the GPU (it never does), pass their output through and exit with
@@ -100,6 +138,8 @@ def main():
     ap.add_argument("--no-p2p", action="store_true", help="N>1: halos through the torch.distributed callback only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path with all ranks on cuda:0 of a one-GPU box (host-staged transport)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this invocation (two rocprofv3 --pmc passes over a child process, ~20 s): read the committed capture")
     ap.add_argument("--native-rccl", action="store_true",
                     help="N>1: libmgx.so's own RCCL communicator instead of the torch.distributed callbacks (opt-in: never run on more than one GPU yet)")
     args = ap.parse_args()
@@ -107,6 +147,12 @@ def main():
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(args.gpus)
+
+    # N = 1: the dominant kernel's HBM traffic from the PMC counters, measured now, in child processes, before this process touches the GPU
+    live_kname = (f"k_relax_nz<{args.size[2]}, true, {'true' if args.method == 'RB' else 'false'}, 3, true, true>" if args.size[2] == 64 else None)
+    traffic_live = None
+    if args.gpus == 1 and not args.no_live_traffic and live_kname and "WORLD_SIZE" not in os.environ:
+        traffic_live = live_traffic(*args.size, args.method, live_kname)
 
     import torch
     import torch.distributed as dist
@@ -408,6 +454,11 @@ def main():
                                "command (scripts/capture_profiles.sh), FETCH x2 (the guide's gfx950 correction, calibrated on an 8-B/lane read of known size)")
         except Exception:
             pass
+    if traffic_live is not None:
+        traffic = traffic_live
+        traffic_src = ("measured in this invocation: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate, with --kernel-trace only) over a child process running "
+                       "level-1 sweeps of the same workload (scripts/sweep_time.py) before the timed process touched the GPU; FETCH x2 (the guide's gfx950 correction, "
+                       "calibrated in profiles/r04_pmc_traffic.json on an 8-B/lane read of known size), WRITE exact; the largest dispatch of the kernel")
     out = None
     if rank == 0:
         scale = npx * npy

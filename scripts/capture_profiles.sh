@@ -15,7 +15,7 @@ stats() {  # $1 = tag, rest = program
   cp $(ls $OUT/${R}_${tag}/*/*_kernel_stats.csv | head -1) $ROOT/profiles/${R}_${tag}_kernel_stats.csv
 }
 # 1. the driver's bench command (N=1 defaults)
-stats bench python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 || exit 1
+stats bench python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-live-traffic || exit 1
 # 2. V-cycles only (no set-up noise in the averages)
 stats vcycle python3 $ROOT/scripts/profile_vcycle.py 512 512 64 FC 20 || exit 1
 # 3. BASELINE config 5's level-1 shape (nz = 128): sweeps, and V-cycles of the 512x512x128 and of the real 512x1024x128 block
@@ -26,8 +26,8 @@ stats config5_512x1024x128 python3 $ROOT/scripts/profile_vcycle.py 512 1024 128 
 timeout -k 10 280 rocprofv3 --kernel-trace --output-format csv -d $OUT/${R}_solve -- python3 $ROOT/scripts/profile_solve.py 512 512 64 FC 10 > $OUT/${R}_solve.log 2>&1 || exit 1
 python3 $ROOT/scripts/solve_breakdown.py $(ls $OUT/${R}_solve/*/*_kernel_trace.csv | head -1) 10 > $ROOT/profiles/${R}_solve_breakdown.txt || exit 1
 # 4. HBM traffic of the dominant kernels, same bench command, two PMC passes
-timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_fetch -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_fetch.log 2>&1 || exit 1
-timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_write -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 > $OUT/${R}_pmc_write.log 2>&1 || exit 1
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_fetch -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 --no-live-traffic > $OUT/${R}_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${R}_pmc_write -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sweep-reps 3 --no-live-traffic > $OUT/${R}_pmc_write.log 2>&1 || exit 1
 python3 $ROOT/scripts/pmc_summary.py $(ls $OUT/${R}_pmc_fetch/*/*_counter_collection.csv | head -1) $(ls $OUT/${R}_pmc_write/*/*_counter_collection.csv | head -1) 16777216 > $ROOT/profiles/${R}_pmc_traffic.json || exit 1
 # 5. the reference's timer table (mg_tictoc format) of a 5-iteration solve, after an untimed warm-up (scripts/tictoc_table.py)
 timeout -k 10 120 python3 $ROOT/scripts/tictoc_table.py $ROOT/profiles/${R}_tictoc_512x512x64_FC_5it.txt FC > $OUT/${R}_tictoc.log 2>&1 || exit 1
