@@ -107,6 +107,9 @@ int mgx_level_dims(int lev, int *nx, int *ny, int *nz);
 /* sequential-order red-black, windowed walk (option "rbseq_window"): the level's contraction bound rho = max |ag5| + |ag8| (-1: not a red-black
  * solver with cmatrix='real') and the planes of warm-up chosen from it (0 = the walk over the whole level stays).  No Fortran counterpart. */
 int mgx_rbseq_window_info(int lev, double *rho, int *planes);
+/* ... and the rows (from the bottom) its correction reaches: above the last row where max over the columns of |g(k) / g(1)| exceeds 2^-64 nothing is
+ * read or written (option "rbseq_rowcut"); nz = every row. */
+int mgx_rbseq_window_rows(int lev, int *rows);
 /* out[0..9] = npx,npy,incx,incy,gather,ngx,ngy,key,color,0 ; out[10..17] = neighbours S,E,N,W,SW,SE,NE,NW (-1 = none) */
 int mgx_level_info(int lev, int *out);
 /* Pure host logic of find_grid_levels / define_grid_dims / define_neighbours / define_gather_informations
@@ -187,6 +190,10 @@ int mgx_set_verbose(int level);
  *   0.03-0.04 on the seamount problem); otherwise, and with 0, the walk over the whole level ("rbseq_fuse").  Not the same bits as that
  *   walk (a truncation of 2^-64 of the largest increment), inside the same tolerances (tests: 1e-12 per relax call against "rb_exact").
  *   Read-only: "rbseq_window_colours" (colours done that way since mgx_init).
+ * "rbseq_rowcut" (default 1): the correction p = y + g s of the windowed walk stops at the last row it reaches -- g = T^-1 e1 decays away from the bottom
+ *   row, and above the last row where max over the columns of |g(k) / g(1)| exceeds 2^-64 (found with the coefficients: mgx_rbseq_window_rows) the
+ *   correction is below 2^-63 of the largest increment: those rows are neither read nor written (55 of 64 rows on level 1 of 512x512x64, 56 of 128 at
+ *   nz = 128); 0 = every row (A/B).
  * "coarsest_direct" (default 1; MGX_COARSEST_DIRECT=n): inside a cycle the coarsest level is entered with p = 0 and left after relax(nlevs, ns_coarsest)
  *   (mg_solvers.f90:117,144): a fixed linear map of b.  Its matrix is built with the level's own relax kernel from the unit vectors whenever the
  *   coefficients change (lazily, at the first cycle after) and the solve becomes one matrix-vector product (mgx_relax_coarse.hip: k_coarse_direct; closed,

@@ -48,6 +48,7 @@ _SIGS = {
     "mgx_nlevs": (C.c_int, []),
     "mgx_level_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgx_rbseq_window_info": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "mgx_rbseq_window_rows": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "mgx_level_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "mgx_level_table": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_int)]),
     "mgx_get_field": (C.c_int, [C.c_int, C.c_int, _DP]),

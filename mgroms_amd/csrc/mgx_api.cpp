@@ -44,7 +44,10 @@ int mgxk_set_rbseq_timeout(double);
 void mgxk_rbseq_apply(hipStream_t, const LevView *, int, Sides, int);
 void mgxk_rbseq_rho(hipStream_t, const LevView *, double *);
 int mgxk_rbseq_window_planes(double);
-int mgxk_rbseq_window(hipStream_t, const LevView *, int, Sides, int, int);
+int mgxk_rbseq_window(hipStream_t, const LevView *, int, Sides, int, int, int);
+void mgxk_rbseq_gdecay(hipStream_t, const LevView *, double *);
+int mgxk_rbseq_window_rows(const double *, int);
+void mgxk_rbseq_d0(hipStream_t, const LevView *, int);
 int mgxk_coarse_direct_cells(const LevView *);
 int mgxk_coarse_direct_slabs(int);
 int mgxk_coarse_direct_build(hipStream_t, const LevView *, int, int, int, Sides, int, double *, long long, double *);
@@ -136,6 +139,7 @@ struct Level {
   unsigned long long p2p_gseq = 0;
   unsigned int *ksp_done = nullptr; unsigned int ksp_seq = 0;  // per-plane progress counters of the persistent mid-level relax (k_relax_ksp) and their common value
   unsigned int *rbs_flag = nullptr; unsigned int rbs_seq = 0;  // progress word of the sequential-order red-black walk and the number of its launches (mgx_rbseq.hip: k_rbseq_scan, FUSE)
+  double *gdec = nullptr; std::vector<double> gdec_h; int rbs_rows = 0;  // per row the largest |g(k) / g(1)| of the level (k_rbseq_gdecay) and the rows the correction reaches (mgxk_rbseq_window_rows)
   double rbs_rho = -1.0; int rbs_m = 0;  // sequential-order red-black, windowed walk (k_rbseq_window): rho = max |ag5| + |ag8| of the level, found at set-up, and the planes of warm-up it asks for (0 = none: the walk over the whole level)
   double *p1b = nullptr;        // second k=1 snapshot buffer (red-black on closed levels: one snapshot launch per relax call)
   double *zy_store, *zx_store;  // slope arrays; v.zy/v.zx point here while the matrix is the one define_matrices built
@@ -213,6 +217,7 @@ struct State {
   double *cd_pb = nullptr, *cd_M = nullptr, *cd_part = nullptr; unsigned int *cd_cnt = nullptr;
   int cd_n = 0, cd_valid = 0, cd_method = -1, cd_mode = -1, cd_nsweeps = -1;   // cd_n: -1 = the level has no instance
   long long n_direct = 0;   // coarsest solves done that way
+  int rbseq_rowcut = 1;  // option "rbseq_rowcut" (A/B): the windowed walk's correction stops at the last row it reaches to 2^-64 (Level::rbs_rows); 0 = every row
   int rbseq_window = 1;  // option "rbseq_window" / MGX_NO_RBSEQ_WINDOW=1: walk and correction of a colour by the windowed walk (k_rbseq_window: no hand-off, no walk over the whole level) on the levels whose contraction bound allows it (Level::rbs_m)
   long long n_window = 0;  // colours done that way
   double *rho_dev = nullptr, rho_host[32];  // the levels' rho (k_rbseq_rho) on the device and after the set-up's copy
@@ -598,7 +603,7 @@ int relax(int lev, int nsweeps) {
         // snapshot launch per relax call; with neighbours the halo part changes with every exchange
         if (S.real && !chain && !(seq && closed && !(it == 1 && rb == 1))) { mgxk_snapshot_k1(S.stream, &L.v); S.n_launch++; }
         // (seq, wide half-rows: the pass also leaves the walk's d0 = y(k=1) - snapshot in u1 where its kernel can -- one launch less)
-        L.v.d0w = (seq && S.rbseq_d0_in_pass && mgxk_rbseq_wants_d0(&L.v)) ? L.v.u1 : nullptr;
+        L.v.d0w = (seq && S.rbseq_d0_in_pass && (mgxk_rbseq_wants_d0(&L.v) || (S.rbseq_window && L.rbs_m > 0))) ? L.v.u1 : nullptr;
         const int pass = mgxk_relax_colour(S.stream, &L.v, 1, 1, L.nx, -1, rb, S.real, S.real, ph); S.n_launch++;
         L.v.d0w = nullptr;
         int fused = pass & 1;
@@ -608,7 +613,10 @@ int relax(int lev, int nsweeps) {
           // (ny > 2048) would have to run plane by plane: refuse loudly rather than fall back to another iteration
           // small levels whose pass left d0 in u1: walk and correction in one launch, every workgroup walking for itself (k_rbseq_walk_apply)
           // the windowed walk where the level's contraction bound allows it (k_rbseq_window): one launch, no hand-off, no walk over the level
-          if (have_d0 && S.rbseq_window && L.rbs_m > 0 && mgxk_rbseq_window(S.stream, &L.v, rb, ph, closed ? 1 : 0, L.rbs_m)) {
+          if (S.rbseq_window && L.rbs_m > 0) {
+            if (!have_d0) { mgxk_rbseq_d0(S.stream, &L.v, rb); S.n_launch++; }   // (the nz = 128 colour pass does not leave it)
+          }
+          if (S.rbseq_window && L.rbs_m > 0 && mgxk_rbseq_window(S.stream, &L.v, rb, ph, closed ? 1 : 0, L.rbs_m, S.rbseq_rowcut ? L.rbs_rows : L.nz)) {
             S.n_launch++; S.n_window++; fused = 1;
             CHK(fill_halo_js(L, L.v.p, fused));
             continue;
@@ -976,9 +984,10 @@ int gather2d(Level &L, double *src_tmp, double *dst) {
 static void set_window_planes() {
   for (int l = 0; l < S.nlevs && l < 32; l++) {
     Level &L = S.lev[l];
-    if (!L.v.gk || !S.rho_dev) { L.rbs_rho = -1.0; L.rbs_m = 0; continue; }
+    if (!L.v.gk || !S.rho_dev) { L.rbs_rho = -1.0; L.rbs_m = 0; L.rbs_rows = L.nz; continue; }
     L.rbs_rho = S.rho_host[l];
     L.rbs_m = mgxk_rbseq_window_planes(L.rbs_rho);
+    L.rbs_rows = (L.gdec && !L.gdec_h.empty()) ? mgxk_rbseq_window_rows(L.gdec_h.data(), L.nz) : L.nz;
     if (S.verbose > 1 && S.rank == 0) printf(" level %d: red-black walk contracts by %.4g per plane: %d planes of warm-up%s\n", l + 1, L.rbs_rho, L.rbs_m, L.rbs_m ? "" : " (none: the walk over the whole level stays)");
   }
 }
@@ -1038,6 +1047,11 @@ int define_matrices() {
     mgxs_pivots(S.stream, &L.v); S.n_launch++;
     if (L.v.gk) { mgxk_rbseq_setup(S.stream, &L.v); S.n_launch++; }
     if (L.v.gk && S.rho_dev && l < 32) { mgxk_rbseq_rho(S.stream, &L.v, S.rho_dev + l); S.n_launch++; }
+    if (L.v.gk && L.gdec) {
+      HIPCHK(hipMemsetAsync(L.gdec, 0, (size_t)L.nz * sizeof(double), S.stream));
+      mgxk_rbseq_gdecay(S.stream, &L.v, L.gdec); S.n_launch++;
+      HIPCHK(hipMemcpyAsync(L.gdec_h.data(), L.gdec, (size_t)L.nz * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    }
     L.v.zy = L.zy_store; L.v.zx = L.zx_store;
     if (L.nz <= 1024) { mgxk_convert2(S.stream, &L.v, L.zy_store, L.zx_store, L.g.szy); S.n_launch++; }
     else { mgxk_convert(S.stream, &L.v, L.zy_store, L.g.szy, 1, 0, 0); mgxk_convert(S.stream, &L.v, L.zx_store, L.g.szx, 1, 0, 0); S.n_launch += 2; }
@@ -1516,6 +1530,7 @@ int mgx_init(int nx, int ny, int nz, int npx, int npy, int rank, const mgx_param
     L.v.gk = L.v.ag58 = L.v.u1 = nullptr; L.v.d0w = nullptr;
     if (S.method == M_RB && S.real) {  // sequential-order red-black (mgx_rbseq.hip): +8 B per cell
       CHK(dmalloc(&L.v.gk, L.n3js));
+      CHK(dmalloc(&L.gdec, (size_t)L.nz)); L.gdec_h.assign((size_t)L.nz, 0.0);
       CHK(dmalloc(&L.v.ag58, (size_t)2 * (L.nx + 2) * L.v.RS)); CHK(dmalloc(&L.v.u1, (size_t)(L.nx + 2) * L.v.RS));
       { double *q = nullptr; CHK(dmalloc(&q, (size_t)(L.nx / 8 + 2) * 8 + 16)); L.rbs_flag = (unsigned int *)q; L.rbs_seq = 0; }  // one word per chunk of 8 planes, 64 B apart (zeroed by dmalloc): what the walk has handed to the correction workers
     }
@@ -1769,6 +1784,7 @@ int mgx_set_option(const char *name, int value) {
   else if (streq(name, "restrict_chain")) S.use_chain = value;
   else if (streq(name, "rbseq_fuse")) S.rbseq_fuse = value;
   else if (streq(name, "rbseq_window")) S.rbseq_window = value;
+  else if (streq(name, "rbseq_rowcut")) S.rbseq_rowcut = value;
   else if (streq(name, "coarsest_direct")) S.coarsest_direct = value;
   else if (streq(name, "overlap")) S.overlap = value;
   else if (streq(name, "ksp")) { S.use_ksp = value; if (value) S.ksp_down = 0; }  // switching it on again also clears a time-out of this solver
@@ -1817,6 +1833,7 @@ int mgx_get_option(const char *name, int *value) {
   else if (streq(name, "restrict_chain")) *value = S.use_chain;
   else if (streq(name, "rbseq_fuse")) *value = S.rbseq_fuse;
   else if (streq(name, "rbseq_window")) *value = S.rbseq_window;
+  else if (streq(name, "rbseq_rowcut")) *value = S.rbseq_rowcut;
   else if (streq(name, "coarsest_direct")) *value = S.coarsest_direct;
   else if (streq(name, "coarsest_direct_solves")) *value = (int)S.n_direct;
   else if (streq(name, "rbseq_window_colours")) *value = (int)S.n_window;
@@ -1883,6 +1900,7 @@ int mgx_synchronize(void) { NEED_INIT(); return sync_stream(); }
 int mgx_nlevs(void) { return S.inited ? S.nlevs : 0; }
 int mgx_level_dims(int lev, int *nx, int *ny, int *nz) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *nx = L.nx; *ny = L.ny; *nz = L.nz; return 0; }
 int mgx_rbseq_window_info(int lev, double *rho, int *planes) { NEED_LEV(lev); const Level &L = S.lev[lev - 1]; *rho = L.rbs_rho; *planes = L.rbs_m; return 0; }
+int mgx_rbseq_window_rows(int lev, int *rows) { NEED_LEV(lev); *rows = S.lev[lev - 1].rbs_rows; return 0; }
 int mgx_level_info(int lev, int *out) {
   NEED_LEV(lev);
   const Level &L = S.lev[lev - 1];
@@ -1944,6 +1962,11 @@ int mgx_set_field(int lev, int field, const double *host) {
     if (L.v.gk && S.rho_dev && lev <= 32) {
       HIPCHK(hipMemsetAsync(S.rho_dev + lev - 1, 0, sizeof(double), S.stream));
       mgxk_rbseq_rho(S.stream, &L.v, S.rho_dev + lev - 1);
+      if (L.gdec) {
+        HIPCHK(hipMemsetAsync(L.gdec, 0, (size_t)L.nz * sizeof(double), S.stream));
+        mgxk_rbseq_gdecay(S.stream, &L.v, L.gdec);
+        HIPCHK(hipMemcpyAsync(L.gdec_h.data(), L.gdec, (size_t)L.nz * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+      }
       HIPCHK(hipMemcpyAsync(S.rho_host, S.rho_dev, sizeof S.rho_host, hipMemcpyDeviceToHost, S.stream));
       CHK(sync_stream());
       set_window_planes();

@@ -546,7 +546,7 @@ constexpr int RBW_MAXM = 48;
 // 0.306-0.310: the walk costs ~6 us of the launch's ~45 (201 MB algorithmic, 210 MB counted: profiles/r04_pmc_traffic_rb_window.json) -- the dependent
 // chain of 14 steps in ONE wave that shares its SIMD's issue slots with three row waves; at raised priority (s_setprio) ~4 of the 6 come back.
 template <int CPL, int KR, bool SNAPW, int RBW_D = 8>
-__global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz, int prio) {
+__global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides ph, int m, int nt, int xmap, int nch, int nkz, int prio, int kcut) {
   __shared__ double ul[64 * CPL + 2];   // u of plane i-1 over the window at 1 + (column - w0); a zero on either side
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nyh = L.ny >> 1;
   // block -> (chunk, plane, row group).  XCD-aware where the planes divide by 8 (xmap): workgroup b runs on XCD b % 8, which takes a contiguous
@@ -557,6 +557,7 @@ __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides p
     const int b = blockIdx.x, x = b & 7, r = b >> 3, per = nch * nkz;
     i = 1 + x * (L.nx >> 3) + r / per; ch = r % nch; kz = (r / nch) % nkz;
   } else { ch = blockIdx.x; i = 1 + blockIdx.y; kz = blockIdx.z; }
+  if (kz * 4 * KR >= kcut) return;   // (rows the correction does not reach: see kcut below; the whole workgroup)
   const int w0 = CPL == 1 ? 0 : ch * 64 - 32;
   const long long RS = L.RS;
   const int jh = ch * 64 + lane;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides p
     const double *__restrict__ g = L.gk;
     c5 = L.cA[4][o + c]; c8 = L.cA[7][o + c];
 #pragma unroll
-    for (int t = 0; t < KR; t++) { const long long ko = o + (long long)(k0 + t) * RS + c; pv[t] = p[ko]; gv[t] = ld_rt(g + ko, nt); }
+    for (int t = 0; t < KR; t++) if (k0 + t < kcut) { const long long ko = o + (long long)(k0 + t) * RS + c; pv[t] = p[ko]; gv[t] = ld_rt(g + ko, nt); }
   }
   __syncthreads();
   if (wv == 4 || !live) return;
@@ -638,6 +639,7 @@ __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides p
 #pragma unroll
   for (int t = 0; t < KR; t++) {
     const int k = k0 + t;
+    if (k >= kcut) break;   // (wave-uniform)
     const long long ro = (long long)k * RS;
     const double v = pv[t] + gv[t] * s;
     p[o + ro + c] = v;
@@ -647,6 +649,33 @@ __global__ __launch_bounds__(320) void k_rbseq_window(LevView L, int rb, Sides p
       L.p1[(long long)i * L.RS + c] = v;
       mirror_store(L2, L.p1, 0, j, i, c, v, ph);
     }
+  }
+}
+
+// kcut: how far up a column the correction reaches.  g = T^-1 e1 decays away from the bottom row (the column matrix is diagonally dominant: by 0.4
+// per row on level 1 of the seamount problem), and the correction of row k is g(k) s = (g(k) / g(1)) * (g(1) s), g(1) s being the bottom row's -- at most
+// twice the largest increment u.  Above the last row where max over the columns of |g(k) / g(1)| exceeds 2^-64 the correction is below 2^-63 of the
+// largest increment -- the same order as the window's truncation -- and those rows are neither read nor written: 55 of 64 rows at 512x512x64,
+// 56 of 128 at nz = 128 (BASELINE config 5's columns), every row on the coarser levels.  out[k-1] = that maximum, per row (non-negative doubles
+// order like their bit patterns).
+__global__ __launch_bounds__(256) void k_rbseq_gdecay(LevView L, unsigned long long *out) {
+  __shared__ double red[4];
+  const int k = blockIdx.y, ncol = L.nx * L.ny;
+  double v = 0.0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < ncol; t += gridDim.x * 256) {
+    const int i = 1 + t / L.ny, jj = 1 + t % L.ny;
+    const long long o = (long long)i * L.plane + jpos(L, jj);
+    const double g1 = L.gk[o], gkv = L.gk[o + (long long)k * L.RS];
+    const double r = __builtin_fabs(gkv) / __builtin_fabs(g1);
+    v = !(r <= v) ? r : v;   // (a NaN -- 0 / 0 in a degenerate column -- wins: the cut is then refused)
+  }
+  for (int sft = 32; sft >= 1; sft >>= 1) { const double ov = __shfl_xor(v, sft); v = !(ov <= v) ? ov : v; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) v = !(red[w] <= v) ? red[w] : v;
+    if (v != v) v = __builtin_inf();
+    atomicMax(out + k, (unsigned long long)__double_as_longlong(v));
   }
 }
 
@@ -829,6 +858,24 @@ int mgxk_rbseq_walk_apply(hipStream_t st, const LevView *L, int rb, Sides ph, in
 void mgxk_rbseq_rho(hipStream_t st, const LevView *L, double *out) {
   hipLaunchKernelGGL(k_rbseq_rho, dim3((L->ny + 63) / 64, (L->nx + 3) / 4), dim3(64, 4), 0, st, *L, (unsigned long long *)out);
 }
+// per row k = 1..nz the maximum over the columns of |g(k) / g(1)| into out[0..nz-1] (device memory, zero before the call)
+void mgxk_rbseq_gdecay(hipStream_t st, const LevView *L, double *out) {
+  const int ncol = L->nx * L->ny;
+  int gx = (ncol + 255) / 256; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_rbseq_gdecay, dim3(gx, L->nz), dim3(256), 0, st, *L, (unsigned long long *)out);
+}
+// rows (from the bottom) the correction reaches: the last one whose decay figure exceeds 2^-64 (all of them when none falls below, or when one is not a number)
+int mgxk_rbseq_window_rows(const double *decay, int nz) {
+  int k = nz;
+  while (k > 1 && decay[k - 1] <= 5.421010862427522e-20) k--;   // 2^-64
+  for (int q = 0; q < nz; q++) if (!(decay[q] >= 0.0) || decay[q] > 1e300) return nz;
+  return k;
+}
+// d0 = y(k=1) - snapshot of the colour into u1, where the colour pass could not leave it (k_relax_tall)
+void mgxk_rbseq_d0(hipStream_t st, const LevView *L, int rb) {
+  const int nyh = L->ny / 2;
+  hipLaunchKernelGGL(k_rbseq_d0, dim3((nyh + WAVE - 1) / WAVE, (L->nx + 3) / 4), dim3(WAVE, 4), 0, st, *L, rb);
+}
 // planes of warm-up after which a walk started from zero has forgotten its start to 2^-64: rho^m <= 2^-64; 0 = too many (or rho not a number)
 int mgxk_rbseq_window_planes(double rho) {
   if (!(rho >= 0.0) || rho >= 1.0) return 0;
@@ -838,9 +885,10 @@ int mgxk_rbseq_window_planes(double rho) {
 }
 // (b) + (c) by the windowed walk (k_rbseq_window); needs d0 in u1 (the colour pass or k_rbseq_d0 wrote it) and m from mgxk_rbseq_window_planes.
 // Returns 1 when launched.
-int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, int m) {
+int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, int m, int kcut) {
   const int nyh = L->ny / 2, nz = L->nz;
   if (L->gk == nullptr || m < 1 || m > RBW_MAXM || nyh < 1 || (L->ny & 1) || L->nx > 65535) return 0;
+  if (kcut < 1 || kcut > nz) kcut = nz;
   const int kr = nz % 64 == 0 ? 16 : (nz % 32 == 0 ? 8 : (nz % 16 == 0 ? 4 : (nz % 8 == 0 ? 2 : (nz % 4 == 0 ? 1 : 0))));
   if (!kr || nz / (4 * kr) > 65535) return 0;
   mgx_before_launch();
@@ -853,8 +901,8 @@ int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int sn
   const int xmap = !no_xmap && L->nx % 8 == 0 && (long long)nch * L->nx * nkz < (1LL << 31);
   const dim3 grd = xmap ? dim3(nch * L->nx * nkz) : dim3(nch, L->nx, nkz), blk(320);
 #define WIN_CASE(CPLV, KRV)                                                                                          \
-  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio); \
-    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio); }
+  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); \
+    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); }
 #define WIN_KR(CPLV) { if (kr == 16) WIN_CASE(CPLV, 16) else if (kr == 8) WIN_CASE(CPLV, 8) else if (kr == 4) WIN_CASE(CPLV, 4) else if (kr == 2) WIN_CASE(CPLV, 2) else WIN_CASE(CPLV, 1) }
   if (cpl == 1) WIN_KR(1) else WIN_KR(2)
 #undef WIN_KR

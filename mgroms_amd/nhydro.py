@@ -216,6 +216,13 @@ def rbseq_window_info(lev):
     return rho.value, m.value
 
 
+def rbseq_window_rows(lev):
+    """rows (from the bottom) the windowed walk's correction reaches on the level (option "rbseq_rowcut"); nz = every row."""
+    r = C.c_int()
+    check(lib().mgx_rbseq_window_rows(lev, C.byref(r)))
+    return r.value
+
+
 class _Level:
     """grid(lev) (mg_grids.f90:24-65): dims, decomposition info and host copies of the level's arrays."""
 

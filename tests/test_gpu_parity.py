@@ -304,7 +304,8 @@ def test_rb_sequential_order_fused_launch_bounded_waits(mg):
 
 
 @pytest.mark.parametrize("dims,geom", [((32, 512, 16), "seamount"), ((64, 256, 32), "rndtopo"), ((48, 96, 16), "seamount"), ((16, 1024, 8), "seamount"),
-                                       ((144, 256, 8), "rndtopo"), ((48, 160, 16), "rndtopo"), ((20, 160, 4), "seamount")])
+                                       ((144, 256, 8), "rndtopo"), ((48, 160, 16), "rndtopo"), ((20, 160, 4), "seamount"),
+                                       ((16, 128, 64), "seamount"), ((16, 64, 128), "seamount")])
 def test_rb_sequential_order_windowed_walk(mg, dims, geom):
     """Option "rbseq_window" (default 1): walk and correction of a colour in one launch without a walk over the whole level -- every workgroup
     walks the m planes in front of its own over its chunk of columns +- 32, from zero (mgx_rbseq.hip: k_rbseq_window).  m comes from the
@@ -312,7 +313,8 @@ def test_rb_sequential_order_windowed_walk(mg, dims, geom):
     against the same maximum formed from the oracle's coefficients, m against it, the colours really done that way, and three sweeps per level
     from a rough random state against the oracle's sequential loop (1e-12 of max|p|) AND against the walk over the whole level
     ("rbseq_window" = 0: 1e-14 -- a truncation of 2^-64 of the largest increment per colour).  Shapes: half-rows of 256 / 128 / 48 / 512 columns, ragged
-    ones (80 = a full chunk + 16 columns, 40), a plane count that is not a multiple of 8 (plain block order), nz = 4 (one row per wave)."""
+    ones (80 = a full chunk + 16 columns, 40), a plane count that is not a multiple of 8 (plain block order), nz = 4 (one row per wave), tall columns (nz = 64 and 128: the correction is cut
+    where g has decayed; the nz = 128 colour pass leaves no d0, k_rbseq_d0 runs)."""
     nx, ny, nz = dims
     o = _setup(mg, nx, ny, nz, geom, relax_method="RB")
     rng = np.random.default_rng(47)
@@ -353,6 +355,73 @@ def test_rb_sequential_order_windowed_walk(mg, dims, geom):
         assert res[1][1] == 6 or (lev >= 2 and res[1][1] == 0 and g.nx * g.ny * g.nz <= 8192), (lev, res[1][1], g.nx, g.ny, g.nz)
         assert np.abs(res[1][0] - c).max() <= 1e-12 * np.abs(c).max(), (lev, np.abs(res[1][0] - c).max() / np.abs(c).max())
         assert np.abs(res[1][0] - res[0][0]).max() <= 1e-14 * np.abs(c).max(), (lev, np.abs(res[1][0] - res[0][0]).max() / np.abs(c).max())
+        # the correction stops at the last row it reaches to 2^-64 ("rbseq_rowcut"): g = T^-1 e1 decays away from the bottom row -- whether a level is cut depends on
+        # dz / dx (test_rb_windowed_walk_stops_where_the_correction_has_decayed builds a case that is); against every row corrected: 1e-14
+        rows = mg.nhydro.rbseq_window_rows(lev)
+        gk = np.abs(x / x[..., :1]).reshape(-1, n).max(0)
+        assert 1 <= rows <= g.nz, (lev, rows)
+        assert rows == g.nz or gk[rows:].max() <= 2.0 ** -64, (lev, rows, gk)
+        assert rows == 1 or gk[rows - 1] > 2.0 ** -64, (lev, rows, gk)
+        if res[1][1] == 6 and rows < g.nz:
+            mg.nhydro.set_option("rbseq_rowcut", 0)
+            try:
+                g.set("p", p); g.set("b", b); mg.fill_halo(lev, "p")
+                mg.relax(lev, 3)
+                full = g.get("p")
+            finally:
+                mg.nhydro.set_option("rbseq_rowcut", 1)
+            assert np.abs(res[1][0] - full).max() <= 1e-14 * np.abs(c).max(), (lev, np.abs(res[1][0] - full).max() / np.abs(c).max())
+
+
+@pytest.mark.parametrize("dims", [(16, 128, 64), (16, 64, 128)])
+def test_rb_windowed_walk_stops_where_the_correction_has_decayed(mg, dims):
+    """Option "rbseq_rowcut" (default 1) on columns that are tall against their width (the seamount's geometry with dx, dy scaled to 19 m and the mount flattened
+    accordingly: the cell shape of 512x512x64 and of BASELINE config 5): g = T^-1 e1 decays by a few per cent per row, the bound max |g(k) / g(1)| falls below 2^-64 well inside the
+    column, and the windowed walk's correction neither reads nor writes the rows above (mgx_rbseq_window_rows < nz, checked against the same figure
+    from the oracle's coefficients).  Three sweeps from a rough random state on level 1 against the oracle's sequential loop (1e-12) and against every
+    row corrected (1e-14); nz = 128: the colour pass (k_relax_tall) leaves no d0, k_rbseq_d0 runs in front of the window launch."""
+    from oracle.mgoracle import Oracle, seamount_geometry
+    nx, ny, nz = dims
+    mg.nhydro_init(nx, ny, nz, 1, 1, 0, mg.nhydro.default_params(relax_method="RB"))
+    dx, dy, zeta, h = seamount_geometry(nx, ny, 1, 1, 0)
+    dx = dx * (19.5 / dx.max()); dy = dy * (19.5 / dy.max())
+    h = 4e3 - 0.01 * (4e3 - h)     # ... and the mount flattened with it (the slopes of the real grid, not of a 2 km mount across 300 m)
+    mg.nhydro_matrices(dx, dy, zeta, h, None, 4e3, 0.0, 0.0)
+    o = Oracle(nx, ny, nz, 1, 1, relax_method="RB")
+    for name, a in (("dx", dx), ("dy", dy), ("zeta", zeta), ("h", h)):
+        o.field(name)[...] = a
+    o.matrices(4e3, 0.0, 0.0)
+    cA = o.field("cA", 1)[1:-1, 1:-1]
+    d, dd = cA[..., 0], cA[..., 1]
+    bet = 1.0 / d[..., 0]; x = np.zeros_like(d); gam = np.zeros_like(d); x[..., 0] = bet
+    for k in range(1, nz):
+        gam[..., k] = dd[..., k] * bet
+        bet = 1.0 / (d[..., k] - dd[..., k] * gam[..., k])
+        x[..., k] = (0 - dd[..., k] * x[..., k - 1]) * bet
+    for k in range(nz - 2, -1, -1):
+        x[..., k] -= gam[..., k + 1] * x[..., k + 1]
+    gk = np.abs(x / x[..., :1]).reshape(-1, nz).max(0)
+    rows = mg.nhydro.rbseq_window_rows(1)
+    assert 1 < rows < nz // 2 and gk[rows:].max() <= 2.0 ** -64 < gk[rows - 1], (rows, gk[:rows + 2])
+    rng = np.random.default_rng(61)
+    g = mg.grid(1)
+    p = rng.standard_normal(g._shape("p")); b = rng.standard_normal(g._shape("b"))
+    o.field("p")[...] = p; o.field("b")[...] = b; o.fill_halo(1, "p")
+    o.relax(1, 3)
+    c = o.field("p")
+    res = {}
+    for cut in (1, 0):
+        mg.nhydro.set_option("rbseq_rowcut", cut)
+        try:
+            g.set("p", p); g.set("b", b); mg.fill_halo(1, "p")
+            n0 = mg.nhydro.get_option("rbseq_window_colours")
+            mg.relax(1, 3)
+            assert mg.nhydro.get_option("rbseq_window_colours") - n0 == 6
+            res[cut] = g.get("p")
+        finally:
+            mg.nhydro.set_option("rbseq_rowcut", 1)
+    assert np.abs(res[1] - c).max() <= 1e-12 * np.abs(c).max(), np.abs(res[1] - c).max() / np.abs(c).max()
+    assert np.abs(res[1] - res[0]).max() <= 1e-14 * np.abs(c).max(), np.abs(res[1] - res[0]).max() / np.abs(c).max()
 
 
 def test_rb_sequential_order_window_refused_when_the_walk_contracts_slowly(mg):

@@ -35,7 +35,7 @@ def test_documented_options_exist(built):
     from mgroms_amd._lib import lib
     hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
     names = set(re.findall(r'"([a-z_0-9]+)" \(default', hdr))
-    assert {"rb_seq", "rb_exact", "rbseq_fuse", "rbseq_window", "rbseq_fuse_min", "rbseq_d0_in_pass", "fuse_closing", "restrict_chain", "overlap", "async"} <= names, names
+    assert {"rb_seq", "rb_exact", "rbseq_fuse", "rbseq_window", "rbseq_rowcut", "rbseq_fuse_min", "rbseq_d0_in_pass", "fuse_closing", "restrict_chain", "overlap", "async"} <= names, names
     L = lib()
     v = ctypes.c_int(-12345)
     for n in sorted(names - {"rbseq_timeout_ms", "ksp_timeout_ms", "p2p_timeout_ms"}):   # (device constants: write-only)
