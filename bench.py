@@ -420,6 +420,8 @@ def main():
             if mode == "sequential_order":
                 window_info = {f"level{l}": dict(zip(("rho", "planes"), nhydro.rbseq_window_info(l))) for l in range(1, mg.nlevs() + 1)}
                 window_info["colours_done_by_the_windowed_walk"] = nhydro.get_option("rbseq_window_colours")
+                for l in range(1, mg.nlevs() + 1):
+                    window_info[f"level{l}"]["rows_corrected"] = nhydro.rbseq_window_rows(l)
             also_rb[mode] = {"vcycles_per_sec": 1e3 / rb_ms, "ms_per_step": rb_ms, "sweep_ms": rb_sweep, "solve_p_iteration_ms": rb_it_ms,
                              "roofline_frac": SMOOTHER_BYTES_PER_CELL * nx * ny * nz / (rb_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, "tolerance": tol}
         nhydro.set_option("rb_exact", 1)
@@ -432,7 +434,8 @@ def main():
         also_rb["sweep_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["sweep_ms"] / also_rb["parallel"]["sweep_ms"]
         also_rb["vcycle_ratio_sequential_over_parallel"] = also_rb["sequential_order"]["ms_per_step"] / also_rb["parallel"]["ms_per_step"]
         also_rb["sequential_order"]["how"] = ("per colour: parallel pass (writes the walk's d0), then ONE launch in which every workgroup walks the m planes in front of its own from zero "
-                                              "(the walk contracts by rho per plane, rho^m <= 2^-64: option rbseq_window) and corrects its columns; DESIGN.md 4.4")
+                                              "(the walk contracts by rho per plane, rho^m <= 2^-64: option rbseq_window) and corrects its columns up to the row where T^-1 e1 has decayed to 2^-64 "
+                                              "(option rbseq_rowcut); the coarsest solve of a cycle as one matrix-vector product (coarsest_direct); DESIGN.md 4.4, 4.6")
         also_rb["sequential_order"]["window"] = window_info
 
     # HBM traffic of the dominant kernel from the PMC counters: they cannot be collected inside this run (rocprofv3 must wrap
