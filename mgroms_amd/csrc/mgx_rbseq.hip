@@ -888,16 +888,20 @@ int mgxk_rbseq_window_planes(double rho) {
 int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int snapw, int m, int kcut) {
   const int nyh = L->ny / 2, nz = L->nz;
   if (L->gk == nullptr || m < 1 || m > RBW_MAXM || nyh < 1 || (L->ny & 1) || L->nx > 65535) return 0;
-  if (kcut < 1 || kcut > nz) kcut = nz;
-  const int kr = nz % 64 == 0 ? 16 : (nz % 32 == 0 ? 8 : (nz % 16 == 0 ? 4 : (nz % 8 == 0 ? 2 : (nz % 4 == 0 ? 1 : 0))));
+  int kr = nz % 64 == 0 ? 16 : (nz % 32 == 0 ? 8 : (nz % 16 == 0 ? 4 : (nz % 8 == 0 ? 2 : (nz % 4 == 0 ? 1 : 0))));
   if (!kr || nz / (4 * kr) > 65535) return 0;
+  if (kcut < 1 || kcut > nz) kcut = nz;
+  // the rows the correction reaches, spread over the four row waves of a workgroup (16 of 64 rows: four rows per wave rather than one wave with all
+  // sixteen and three idle), and only the row groups that hold any are launched
+  static const bool no_spread = getenv("MGX_RBW_NO_SPREAD") != nullptr;   // A/B
+  while (!no_spread && kr > 1 && 4 * (kr / 2) >= kcut) kr /= 2;
   mgx_before_launch();
   static const bool no_xmap = getenv("MGX_RBSEQ_WINDOW_NO_XMAP") != nullptr;   // A/B
   // the walking wave at raised priority (s_setprio 3): level-1 sweep 0.3075-0.3150 -> 0.2989-0.3073 ms (three runs each, alternating); MGX_RBW_PRIO=0: A/B
   static const int prio = getenv("MGX_RBW_PRIO") ? atoi(getenv("MGX_RBW_PRIO")) : 1;
   static const int probe_m = getenv("MGX_RBW_PROBE_M") ? atoi(getenv("MGX_RBW_PROBE_M")) : -1;   // timing probe only (wrong results): another number of planes walked
   if (probe_m >= 0) m = probe_m;
-  const int nt = level_streams(L), cpl = nyh <= WAVE ? 1 : 2, nch = (nyh + WAVE - 1) / WAVE, nkz = nz / (4 * kr);
+  const int nt = level_streams(L), cpl = nyh <= WAVE ? 1 : 2, nch = (nyh + WAVE - 1) / WAVE, nkz = (kcut + 4 * kr - 1) / (4 * kr);
   const int xmap = !no_xmap && L->nx % 8 == 0 && (long long)nch * L->nx * nkz < (1LL << 31);
   const dim3 grd = xmap ? dim3(nch * L->nx * nkz) : dim3(nch, L->nx, nkz), blk(320);
 #define WIN_CASE(CPLV, KRV)                                                                                          \
