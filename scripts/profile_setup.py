@@ -16,7 +16,7 @@ nx, ny, nz = (int(a) for a in sys.argv[1:4])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 torch.cuda.set_device(0)
 nhydro.set_verbose(0)
-mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method="FC"))
+mg.nhydro_init(nx, ny, nz, 1, 1, 0, nhydro.default_params(relax_method=(sys.argv[5] if len(sys.argv) > 5 else "FC")))
 geo = seamount_geometry(nx, ny, 1, 1, 0)
 mg.nhydro_matrices(*geo, None, 4e3, 0.0, 0.0)
 torch.cuda.synchronize()
