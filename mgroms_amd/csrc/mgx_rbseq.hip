@@ -905,8 +905,8 @@ int mgxk_rbseq_window(hipStream_t st, const LevView *L, int rb, Sides ph, int sn
   const int xmap = !no_xmap && L->nx % 8 == 0 && (long long)nch * L->nx * nkz < (1LL << 31);
   const dim3 grd = xmap ? dim3(nch * L->nx * nkz) : dim3(nch, L->nx, nkz), blk(320);
 #define WIN_CASE(CPLV, KRV)                                                                                          \
-  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); \
-    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); }
+  { if (snapw) hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, true, (KRV <= 4 ? 4 : 8)>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); \
+    else hipLaunchKernelGGL((k_rbseq_window<CPLV, KRV, false, (KRV <= 4 ? 4 : 8)>), grd, blk, 0, st, *L, rb, ph, m, nt, xmap, nch, nkz, prio, kcut); }
 #define WIN_KR(CPLV) { if (kr == 16) WIN_CASE(CPLV, 16) else if (kr == 8) WIN_CASE(CPLV, 8) else if (kr == 4) WIN_CASE(CPLV, 4) else if (kr == 2) WIN_CASE(CPLV, 2) else WIN_CASE(CPLV, 1) }
   if (cpl == 1) WIN_KR(1) else WIN_KR(2)
 #undef WIN_KR
