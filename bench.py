@@ -89,9 +89,20 @@ def live_traffic(nx, ny, nz, method, kname):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.join(ROOT, "scripts", "sweep_time.py"), str(nx), str(ny), str(nz), method, "3"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            # (a process group of its own: a pass that times out is ended together with the profiled child, so nothing keeps the GPU busy behind the bench)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None
             files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             best = 0.0
             for row in csv.DictReader(open(files[0])):
