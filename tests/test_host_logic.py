@@ -166,3 +166,33 @@ def test_bench_live_traffic_falls_back_without_a_gpu():
         assert time.time() - t0 < 1.0
     finally:
         del os.environ["ROCPROF_TEST_MARK"]
+
+
+def test_windowed_walk_bounds_host_logic(built):
+    """The two host-side decisions of the windowed red-black walk (mgx_rbseq.hip), callable without a GPU: the planes of warm-up from the contraction
+    bound rho (rho^m <= 2^-64, at least 2, none beyond 48 or for a bound that is not a number below one) and the rows the correction reaches from the
+    per-row decay figures (the last one above 2^-64; every row when a figure is not finite)."""
+    import ctypes
+    import math
+    from mgroms_amd._lib import lib
+    L = lib()
+    planes = L.mgxk_rbseq_window_planes
+    planes.restype = ctypes.c_int; planes.argtypes = [ctypes.c_double]
+    for rho in (0.011, 0.025, 0.0385, 0.1, 0.2, 0.39):
+        m = planes(rho)
+        assert m >= 2 and rho ** m <= 2.0 ** -64 and (m == 2 or rho ** (m - 1) > 2.0 ** -64), (rho, m)
+    assert planes(0.0385) == 14 and planes(0.0) == 1 and planes(1e-30) == 2
+    assert planes(0.41) == 0 and planes(0.9) == 0 and planes(1.0) == 0 and planes(1.5) == 0 and planes(-0.1) == 0 and planes(float("nan")) == 0
+    rows = L.mgxk_rbseq_window_rows
+    rows.restype = ctypes.c_int; rows.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+
+    def nrows(v):
+        a = (ctypes.c_double * len(v))(*v)
+        return rows(a, len(v))
+    dec = [0.02 ** k for k in range(64)]
+    k = nrows(dec)
+    assert k == 1 + max(i for i, d in enumerate(dec) if d > 2.0 ** -64) and k < 20
+    assert nrows([1.0, 0.5, 0.25, 0.125]) == 4                      # nothing decays far enough: every row
+    assert nrows([1.0] + [0.0] * 31) == 1
+    assert nrows([1.0, 1e-30, float("inf"), 0.0]) == 4 and nrows([1.0, float("nan"), 0.0, 0.0]) == 4   # a figure that is not finite: no cut
+    assert nrows([1.0, 1e-25, 1e-10, 1e-30]) == 3                  # (not monotone: the LAST row above the threshold counts)
